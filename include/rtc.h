@@ -1,0 +1,277 @@
+/*
+ * rtc.h — C-ABI of the MI355X-native renderer for the per-pixel hot path of
+ * joedane/raytracer-challenge (crate `ch1`):
+ *
+ *     Camera::render / render_async  ->  World::color_at  ->  World::intersect
+ *                                    ->  shade_hit (lighting, shadow, reflect, refract)
+ *
+ * The reference has no FFI of its own (plain Rust `pub` methods); every
+ * entry point below cites the reference item (file:line under ch1/src/) whose job it
+ * takes over, so that a Rust `extern "C"` block binding these names is mechanical
+ * (the stub is shown in INTEGRATION.md).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; nothing unwinds across this boundary;
+ *     every function returns an rtc_status (0 = RTC_OK) unless stated otherwise.
+ *   - all arithmetic on the path is IEEE f64 (vec.rs:7-12, color.rs:5-10), evaluated in
+ *     the reference's operation order with no FMA contraction.
+ *   - matrices are 4x4 row-major `double[16]` (transform.rs:23-27).
+ *   - a canvas is `double[height][width][3]`, row-major, idx = y*width + x
+ *     (canvas.rs:16-22,43-51).
+ *   - functions marked [host] never touch the GPU; functions marked [device] need a
+ *     context and fail with RTC_ERR_DEVICE when no MI355X is usable. There is no CPU
+ *     fallback inside this library.
+ */
+#ifndef RTC_H
+#define RTC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTC_ABI_VERSION 1u
+
+/* ---- status codes (the reference panics instead) -------------------- */
+typedef int32_t rtc_status;
+enum {
+    RTC_OK             = 0,
+    RTC_ERR_SINGULAR   = 1, /* Matrix::inverse on |det| <= 1e-8      transform.rs:35-38,175-177 */
+    RTC_ERR_NO_COLOR   = 2, /* material with neither colour nor pattern  material.rs:328-331    */
+    RTC_ERR_DEVICE     = 3, /* no usable gfx950 device / HIP runtime error                      */
+    RTC_ERR_ARG        = 4, /* null pointer, zero size, row range outside the canvas ...        */
+    RTC_ERR_PARSE      = 5, /* scene description rejected (lua.rs:216,322-326 analogue)         */
+    RTC_ERR_IO         = 6, /* file could not be opened / written     canvas.rs:87-91           */
+    RTC_ERR_NOMEM      = 7,
+    RTC_ERR_UNSUPPORTED= 8  /* e.g. randomised AA resample (camera.rs:84-92), see rtc_camera    */
+};
+
+/* ---- enumerations ------------------------------------------------------------------ */
+enum { /* rtc_shape.kind                        */
+    RTC_SPHERE = 0, /* shape.rs:281-394 */
+    RTC_PLANE  = 1, /* shape.rs:405-498 */
+    RTC_CUBE   = 2  /* shape.rs:500-630 */
+};
+enum { /* rtc_material.pattern_kind              */
+    RTC_PATTERN_NONE     = 0,
+    RTC_PATTERN_TEST     = 1, /* material.rs:48-70   */
+    RTC_PATTERN_STRIPE   = 2, /* material.rs:72-104  */
+    RTC_PATTERN_GRADIENT = 3, /* material.rs:106-136 */
+    RTC_PATTERN_RING     = 4, /* material.rs:138-171 */
+    RTC_PATTERN_CHECKER  = 5, /* material.rs:173-206 */
+    RTC_PATTERN_GRID     = 6  /* material.rs:208-242 */
+};
+enum { /* render mode */
+    RTC_MODE_RENDER       = 0, /* Camera::render: y in 0..vsize-1, x in 0..hsize-1 EXCLUSIVE,
+                                  last row and column stay black        camera.rs:116-126 */
+    RTC_MODE_RENDER_ASYNC = 1  /* Camera::render_async / render_async1: all pixels
+                                                                        camera.rs:128-160 */
+};
+enum { /* render flags (bit set) */
+    RTC_FLAG_NONE      = 0,
+    RTC_FLAG_NO_CULL   = 1u << 0, /* visit every object for every ray (plain brute force); the
+                                     default culls objects with a conservative bound first and
+                                     produces bit-identical results */
+    RTC_FLAG_QUANT_U8  = 1u << 1  /* reserved */
+};
+
+#define RTC_MAX_REFLECTIONS 5u /* Camera::MAX_REFLECTIONS camera.rs:31 */
+#define RTC_EPSILON 0.00000001 /* Vector::EPSILON         vec.rs:16    */
+
+/* ---- flattened world --------------------------------------------------------------- */
+
+/* Material (material.rs:244-254) with its optional pattern flattened in. */
+typedef struct rtc_material {
+    uint32_t pattern_kind;   /* RTC_PATTERN_*; NONE <=> Material.pattern == None           */
+    uint32_t has_color;      /* Material.color.is_some()                                    */
+    double   color[3];
+    double   ambient, diffuse, specular, shininess;
+    double   reflective;     /* Material.reflectiveness                                     */
+    double   transparency;
+    double   refractive_index;
+    double   pat_inv[16];    /* Pattern.xf_inv (inverse of the pattern transform)           */
+    double   pat_a[3];       /* color_a / color_base                                        */
+    double   pat_b[3];       /* color_b / color_grid                                        */
+} rtc_material;              /* 264 bytes */
+
+/* One shape of World.shapes (shape.rs:633-637). `inv` is what the reference stores in the
+ * field misleadingly called `transform` (the INVERSE of the object transform,
+ * shape.rs:300,311); `inv_t` is `transform_transpose` (shape.rs:301,312). Both are carried
+ * explicitly so that a caller can reproduce the stale-transpose quirk of
+ * Plane::set_transform (shape.rs:446-449). */
+typedef struct rtc_shape {
+    uint32_t     kind;       /* RTC_SPHERE / RTC_PLANE / RTC_CUBE                           */
+    uint32_t     world_id;   /* World::add_shape assigns last_world_id+1 (shape.rs:661-667);
+                                only compared for equality (shape.rs:127)                   */
+    double       inv[16];
+    double       inv_t[16];
+    rtc_material material;
+} rtc_shape;                 /* 528 bytes */
+
+/* Light (material.rs:10-31). World has exactly one (shape.rs:635). */
+typedef struct rtc_light {
+    double intensity[3];
+    double position[3];
+} rtc_light;
+
+/* Camera (camera.rs:17-27). */
+typedef struct rtc_camera {
+    uint32_t hsize, vsize;
+    double   fov;
+    double   half_width, half_height, pixel_size;
+    double   view_inv[16];   /* view_transform_inv: inverse of the view matrix camera.rs:35 */
+    uint32_t samples;        /* antialiasing_samples (camera.rs:24). 1 = one ray per pixel.
+                                >1 = the 4 fixed sub-samples of render_pixel
+                                (camera.rs:101-107) averaged; the thread_rng resample branch
+                                (camera.rs:84-92,109-111) is non-deterministic in the
+                                reference and is NOT taken.                                 */
+    uint32_t _pad;
+} rtc_camera;
+
+/* Ray counters. A ray = one call of World::intersect (shape.rs:677). */
+typedef struct rtc_stats {
+    uint64_t rays_primary;   /* color_at from render_pixel          camera.rs:97-105   */
+    uint64_t rays_shadow;    /* is_shadowed, one per shade_hit      shape.rs:688,712   */
+    uint64_t rays_reflect;   /* reflected_color recursion           shape.rs:734-735   */
+    uint64_t rays_refract;   /* refracted_color recursion           shape.rs:764-765   */
+    uint64_t pixels;         /* pixels written by the last render                        */
+    uint64_t _reserved[3];
+} rtc_stats;
+
+/* Per-ray probe record filled by rtc_color_at: the fields of CachedVectors
+ * (shape.rs:58-71) for the ray's FIRST hit. hit_index = position in World.shapes
+ * (insertion order) or -1. */
+typedef struct rtc_hit {
+    int32_t  hit_index;
+    uint32_t inside;
+    uint32_t shadowed;       /* World::is_shadowed(over_point)      shape.rs:712-727   */
+    uint32_t _pad;
+    double   t;
+    double   point[3];
+    double   over_point[3];
+    double   under_point[3];
+    double   eyev[3];
+    double   normal[3];
+    double   reflectv[3];
+    double   n1, n2;         /* compute_refractive; 1.0/1.0 unless the hit material has
+                                transparency != 0 (the only case the reference reads them,
+                                shape.rs:692,752)                                       */
+} rtc_hit;
+
+typedef struct rtc_context rtc_context; /* one GPU + one stream; single-threaded use      */
+typedef struct rtc_world   rtc_world;   /* flattened World resident in HBM                */
+
+/* ==== [host] reference-faithful setup arithmetic =================================== */
+
+/* ABI / build identification. Returns RTC_ABI_VERSION. */
+uint32_t    rtc_abi_version(void);
+const char *rtc_strerror(rtc_status s);
+
+/* Matrix::identity / multiply (transform.rs:44-51, 8-21,31-33). out may alias neither input. */
+void        rtc_matrix_identity(double out[16]);
+void        rtc_matrix_multiply(const double a[16], const double b[16], double out[16]);
+/* Fluent builders: each LEFT-multiplies, `out = new * m` (transform.rs:53-105). out may alias m. */
+void        rtc_matrix_translation(const double m[16], double x, double y, double z, double out[16]);
+void        rtc_matrix_scaling    (const double m[16], double x, double y, double z, double out[16]);
+void        rtc_matrix_rotation_x (const double m[16], double r, double out[16]);
+void        rtc_matrix_rotation_y (const double m[16], double r, double out[16]);
+void        rtc_matrix_rotation_z (const double m[16], double r, double out[16]);
+void        rtc_matrix_shearing   (const double m[16], double xy, double xz, double yx, double yz,
+                                   double zx, double zy, double out[16]);
+/* Matrix::determinant by cofactor expansion along row 0 (transform.rs:130-169). */
+double      rtc_matrix_determinant(const double m[16]);
+/* Matrix::inverse, cofactor method; RTC_ERR_SINGULAR when |det| <= 1e-8 (transform.rs:35-38,175-190). */
+rtc_status  rtc_matrix_inverse(const double m[16], double out[16]);
+void        rtc_matrix_transpose(const double m[16], double out[16]); /* transform.rs:192-202 */
+/* Matrix::make_view_transform(from, to, up) (transform.rs:204-217). */
+void        rtc_view_transform(const double from[3], const double to[3], const double up[3], double out[16]);
+
+/* Camera::new_with_transform(hsize, vsize, fov, view) (camera.rs:33-58): derives
+ * half_width/half_height/pixel_size and stores inverse(view). samples = 1. */
+rtc_status  rtc_camera_init(uint32_t hsize, uint32_t vsize, double fov, const double view[16], rtc_camera *out);
+/* Camera::ray_for_pixel_offset (camera.rs:64-76); ray = {origin xyz, direction xyz}. */
+void        rtc_camera_ray_for_pixel(const rtc_camera *cam, uint32_t x, double x_offset,
+                                     uint32_t y, double y_offset, double ray[6]);
+
+/* Material::default() (white, .1/.9/.9/200, 0/0/1.0; material.rs:273-283,364-369). */
+void        rtc_material_default(rtc_material *out);
+/* {Sphere,Plane,Cube}::new_with_transform_and_material(m, mat) (shape.rs:308-317,436-444,
+ * 525-533): inv = m.inverse(), inv_t = inv.transpose(). world_id is left 0. */
+rtc_status  rtc_shape_init(uint32_t kind, const double transform[16], const rtc_material *mat, rtc_shape *out);
+/* Pattern::set_transform (material.rs:61-63 etc.): mat->pat_inv = inverse(transform). */
+rtc_status  rtc_material_set_pattern(rtc_material *mat, uint32_t pattern_kind, const double a[3],
+                                     const double b[3], const double transform[16]);
+/* Light::default(): white at (-10,10,-10) (material.rs:26-31). */
+void        rtc_light_default(rtc_light *out);
+
+/* Scene loader for the `jamis.yml` vocabulary (ch1/jamis.yml:1-183; the reference ships the
+ * data file but no loader). Parses `text` (NUL-terminated YAML subset),
+ * applies transform lists in listed order (transform.rs:53-69 left-multiplication), starts
+ * materials from Material::default() (lua.rs:187) and assigns world ids like
+ * World::add_shape. On success *shapes_out is a malloc'ed array the caller releases with
+ * rtc_free. Only the first light is used (lua.rs:148-150). */
+rtc_status  rtc_scene_load_yaml(const char *text, rtc_shape **shapes_out, uint32_t *n_out,
+                                rtc_light *light_out, rtc_camera *camera_out,
+                                char *errbuf, size_t errbuf_len);
+rtc_status  rtc_scene_load_yaml_file(const char *path, rtc_shape **shapes_out, uint32_t *n_out,
+                                     rtc_light *light_out, rtc_camera *camera_out,
+                                     char *errbuf, size_t errbuf_len);
+void        rtc_free(void *p);
+
+/* Canvas::write_to_file_simple: ASCII PPM P3 (canvas.rs:86-109) with Color::scale's
+ * truncating, saturating cast and clamp (color.rs:100-114). `rgb` is a host canvas. */
+rtc_status  rtc_canvas_write_ppm(const char *path, const double *rgb, uint32_t width, uint32_t height);
+/* The same encoder into memory: returns bytes needed (excluding NUL); writes at most cap. */
+size_t      rtc_canvas_format_ppm(const double *rgb, uint32_t width, uint32_t height, char *buf, size_t cap);
+
+/* ==== [device] the hot path on one MI355X ========================================== */
+
+/* Create a context on HIP device `device`. `stream` is an existing hipStream_t passed as
+ * void* (e.g. torch's current stream) or NULL for a stream owned by the context. */
+rtc_status  rtc_context_create(int32_t device, void *stream, rtc_context **out);
+void        rtc_context_destroy(rtc_context *ctx);
+rtc_status  rtc_context_synchronize(rtc_context *ctx);
+/* Device facts for reports: name (<= cap bytes), compute units, clock MHz. */
+rtc_status  rtc_context_device_info(rtc_context *ctx, char *name, size_t cap,
+                                    int32_t *compute_units, int32_t *clock_mhz);
+
+/* World::new(light) + add_shape* (shape.rs:642-667): flatten and upload once; the world
+ * stays resident in HBM across renders. Validates materials (RTC_ERR_NO_COLOR). */
+rtc_status  rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t n_shapes,
+                             const rtc_light *light, rtc_world **out);
+void        rtc_world_destroy(rtc_world *w);
+
+/* Camera::render / render_async for canvas rows [y0, y1) into a DEVICE buffer of
+ * (y1-y0)*hsize*3 doubles (row y0 first). Enqueues on the context stream and returns
+ * without synchronising. Row-tiling hook for multi-GPU (each rank renders its rows). */
+rtc_status  rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,
+                            uint32_t mode, uint32_t y0, uint32_t y1, void *d_rgb, uint32_t flags);
+/* Camera::render(&World) -> Canvas with host memory: renders all rows and copies the
+ * canvas into `rgb` (vsize*hsize*3 doubles). Synchronous. `stats` may be NULL. */
+rtc_status  rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,
+                       uint32_t mode, uint32_t flags, double *rgb, rtc_stats *stats);
+/* Ray counters accumulated since the last reset (synchronises the stream). */
+rtc_status  rtc_stats_read(rtc_context *ctx, rtc_stats *out);
+rtc_status  rtc_stats_reset(rtc_context *ctx);
+/* Duration in ms of the most recent rtc_render_rows launch measured with HIP events on the
+ * context stream (synchronises). */
+rtc_status  rtc_last_kernel_ms(rtc_context *ctx, float *ms);
+
+/* World::color_at(ray, remaining) (shape.rs:702-710) for `n` arbitrary host rays
+ * (n x {origin xyz, direction xyz}); writes n x rgb and, if hits != NULL, the hit record
+ * of each ray's first intersection. Synchronous. */
+rtc_status  rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays, uint32_t n,
+                         uint32_t remaining, uint32_t flags, double *rgb, rtc_hit *hits);
+
+/* Device arithmetic probe: applies op (0 sqrt, 1 a/b, 2 pow(a,b), 3 floor, 4 fmod(a,2))
+ * element-wise on the GPU; used by the tests to prove f64 sqrt and division are correctly
+ * rounded on gfx950 (they must be bit-identical to the host's). */
+rtc_status  rtc_device_arith(rtc_context *ctx, uint32_t op, const double *a, const double *b,
+                             uint32_t n, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTC_H */

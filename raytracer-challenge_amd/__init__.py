@@ -1,0 +1,348 @@
+"""raytracer-challenge_amd — MI355X-native renderer for the hot path of joedane/raytracer-challenge.
+
+This package is a thin ctypes binding of ``librtc.so`` (``include/rtc.h``): HIP kernels for
+``Camera::render -> World::color_at -> World::intersect -> shade_hit`` behind a C-ABI, plus the
+host-side setup arithmetic (Matrix / Camera / Shape constructors, the jamis.yml loader, the PPM
+writer). The directory name carries a hyphen; import it through ``_bootstrap.py`` at the repo
+root, which registers it as ``raytracer_challenge_amd``.
+
+There is no CPU fallback: if ``librtc.so`` is missing, or no gfx950 device is usable, the
+calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from pathlib import Path
+
+import numpy as np
+
+from .abi import (RtcCamera, RtcHit, RtcLight, RtcMaterial, RtcShape, RtcStats, Mat16, Vec3,
+                  SPHERE, PLANE, CUBE, MODE_RENDER, MODE_RENDER_ASYNC, PATTERNS, STATUS_NAMES, declare)
+
+PKG = Path(__file__).resolve().parent
+LIB_PATH = PKG / "librtc.so"
+
+_lib = None
+
+
+class RtcError(RuntimeError):
+    def __init__(self, status: int, where: str, detail: str = ""):
+        self.status = status
+        name = STATUS_NAMES.get(status, str(status))
+        super().__init__(f"{where}: {name}" + (f" ({detail})" if detail else ""))
+
+
+def lib() -> C.CDLL:
+    """Load librtc.so (built by ``build.build()`` / ``__graft_entry__.build()``). Fails loudly."""
+    global _lib
+    if _lib is None:
+        if not LIB_PATH.exists():
+            raise RuntimeError(f"{LIB_PATH} is missing: run `python __graft_entry__.py build` (hipcc, gfx950). "
+                               "There is no CPU fallback for the render path.")
+        _lib = C.CDLL(str(LIB_PATH))
+        declare(_lib)
+    return _lib
+
+
+def _check(status: int, where: str, detail: str = "") -> None:
+    if status != 0:
+        raise RtcError(status, where, detail)
+
+
+# ---------------------------------------------------------------------------------------
+# host-side mirror of the reference's setup API (names follow ch1/src/*.rs)
+# ---------------------------------------------------------------------------------------
+class Matrix:
+    """Matrix (transform.rs:23-27) with the fluent, LEFT-multiplying builders (transform.rs:53-105)."""
+
+    __slots__ = ("m",)
+
+    def __init__(self, m=None):
+        self.m = Mat16()
+        if m is None:
+            lib().rtc_matrix_identity(self.m)
+        else:
+            flat = np.asarray(m, dtype=np.float64).reshape(16)
+            for i in range(16):
+                self.m[i] = flat[i]
+
+    @staticmethod
+    def identity() -> "Matrix":
+        return Matrix()
+
+    def _apply(self, fn, *args) -> "Matrix":
+        out = Matrix.__new__(Matrix)
+        out.m = Mat16()
+        fn(self.m, *[C.c_double(a) for a in args], out.m)
+        return out
+
+    def translation(self, x, y, z): return self._apply(lib().rtc_matrix_translation, x, y, z)
+    def scaling(self, x, y, z): return self._apply(lib().rtc_matrix_scaling, x, y, z)
+    def rotation_x(self, r): return self._apply(lib().rtc_matrix_rotation_x, r)
+    def rotation_y(self, r): return self._apply(lib().rtc_matrix_rotation_y, r)
+    def rotation_z(self, r): return self._apply(lib().rtc_matrix_rotation_z, r)
+    def shearing(self, xy, xz, yx, yz, zx, zy): return self._apply(lib().rtc_matrix_shearing, xy, xz, yx, yz, zx, zy)
+
+    def multiply(self, other: "Matrix") -> "Matrix":
+        out = Matrix.__new__(Matrix)
+        out.m = Mat16()
+        lib().rtc_matrix_multiply(self.m, other.m, out.m)
+        return out
+
+    def inverse(self) -> "Matrix":
+        out = Matrix.__new__(Matrix)
+        out.m = Mat16()
+        _check(lib().rtc_matrix_inverse(self.m, out.m), "Matrix.inverse")
+        return out
+
+    def transpose(self) -> "Matrix":
+        out = Matrix.__new__(Matrix)
+        out.m = Mat16()
+        lib().rtc_matrix_transpose(self.m, out.m)
+        return out
+
+    def determinant(self) -> float:
+        return float(lib().rtc_matrix_determinant(self.m))
+
+    @staticmethod
+    def make_view_transform(frm, to, up) -> "Matrix":
+        out = Matrix.__new__(Matrix)
+        out.m = Mat16()
+        lib().rtc_view_transform(Vec3(*frm), Vec3(*to), Vec3(*up), out.m)
+        return out
+
+    def numpy(self) -> np.ndarray:
+        return np.array(list(self.m), dtype=np.float64).reshape(4, 4)
+
+
+def material(color=(1.0, 1.0, 1.0), ambient=0.1, diffuse=0.9, specular=0.9, shininess=200.0, reflective=0.0,
+             transparency=0.0, refractive_index=1.0, pattern=None) -> RtcMaterial:
+    """Material (material.rs:244-254) starting from Material::default() (white). `pattern` is
+    (kind_name, color_a, color_b, Matrix|None) or None; `color=None` means Material.color = None."""
+    m = RtcMaterial()
+    lib().rtc_material_default(C.byref(m))
+    if color is None:
+        m.has_color = 0
+    else:
+        m.has_color = 1
+        for i in range(3):
+            m.color[i] = float(color[i])
+    m.ambient, m.diffuse, m.specular, m.shininess = float(ambient), float(diffuse), float(specular), float(shininess)
+    m.reflective, m.transparency, m.refractive_index = float(reflective), float(transparency), float(refractive_index)
+    if pattern is not None:
+        kind, a, b, xf = pattern
+        xf = xf if xf is not None else Matrix.identity()
+        _check(lib().rtc_material_set_pattern(C.byref(m), PATTERNS[kind], Vec3(*a), Vec3(*b), xf.m), "Pattern.set_transform")
+    return m
+
+
+def _shape(kind: int, transform: Matrix | None, mat: RtcMaterial | None) -> RtcShape:
+    s = RtcShape()
+    t = transform if transform is not None else Matrix.identity()
+    _check(lib().rtc_shape_init(kind, t.m, C.byref(mat) if mat is not None else None, C.byref(s)), "Shape.new_with_transform_and_material")
+    return s
+
+
+def sphere(transform=None, mat=None) -> RtcShape: return _shape(SPHERE, transform, mat)   # shape.rs:308
+def plane(transform=None, mat=None) -> RtcShape: return _shape(PLANE, transform, mat)     # shape.rs:436
+def cube(transform=None, mat=None) -> RtcShape: return _shape(CUBE, transform, mat)       # shape.rs:525
+
+
+def light(position=(-10.0, 10.0, -10.0), intensity=(1.0, 1.0, 1.0)) -> RtcLight:
+    l = RtcLight()
+    for i in range(3):
+        l.position[i] = float(position[i])
+        l.intensity[i] = float(intensity[i])
+    return l
+
+
+class World:
+    """World (shape.rs:633-637): host-side list of shapes + one light; `add_shape` assigns
+    world ids like the reference (shape.rs:661-667)."""
+
+    def __init__(self, lgt: RtcLight | None = None):
+        self.light = lgt if lgt is not None else light()
+        self.shapes: list[RtcShape] = []
+
+    def add_shape(self, s: RtcShape) -> "World":
+        s.world_id = len(self.shapes) + 1
+        self.shapes.append(s)
+        return self
+
+    @staticmethod
+    def default() -> "World":
+        """impl Default for World (shape.rs:784-795)."""
+        w = World()
+        w.add_shape(sphere(Matrix.identity(), material(color=(0.8, 1.0, 0.6), diffuse=0.7, specular=0.2)))
+        w.add_shape(sphere(Matrix.identity().scaling(0.5, 0.5, 0.5)))
+        return w
+
+    def array(self):
+        arr = (RtcShape * max(1, len(self.shapes)))()
+        for i, s in enumerate(self.shapes):
+            arr[i] = s
+        return arr
+
+    def __len__(self):
+        return len(self.shapes)
+
+
+def camera(hsize: int, vsize: int, fov: float, view: Matrix | None = None, samples: int = 1) -> RtcCamera:
+    """Camera::new_with_transform (camera.rs:33-58)."""
+    cam = RtcCamera()
+    v = view if view is not None else Matrix.identity()
+    _check(lib().rtc_camera_init(hsize, vsize, float(fov), v.m, C.byref(cam)), "Camera.new_with_transform")
+    cam.samples = samples
+    return cam
+
+
+def ray_for_pixel(cam: RtcCamera, x: int, y: int, xo: float = 0.5, yo: float = 0.5) -> np.ndarray:
+    out = (C.c_double * 6)()
+    lib().rtc_camera_ray_for_pixel(C.byref(cam), x, C.c_double(xo), y, C.c_double(yo), out)
+    return np.array(list(out))
+
+
+def load_yaml(text: str | None = None, path: str | None = None):
+    """jamis.yml-vocabulary loader -> (World, RtcCamera)."""
+    shapes = C.POINTER(RtcShape)()
+    n = C.c_uint32(0)
+    lgt, cam = RtcLight(), RtcCamera()
+    err = C.create_string_buffer(512)
+    if path is not None:
+        st = lib().rtc_scene_load_yaml_file(str(path).encode(), C.byref(shapes), C.byref(n), C.byref(lgt), C.byref(cam), err, 512)
+    else:
+        st = lib().rtc_scene_load_yaml(text.encode(), C.byref(shapes), C.byref(n), C.byref(lgt), C.byref(cam), err, 512)
+    _check(st, "rtc_scene_load_yaml", err.value.decode(errors="replace"))
+    w = World(lgt)
+    for i in range(n.value):
+        s = RtcShape()
+        C.memmove(C.byref(s), C.byref(shapes[i]), C.sizeof(RtcShape))
+        w.shapes.append(s)
+    lib().rtc_free(shapes)
+    return w, cam
+
+
+def format_ppm(rgb: np.ndarray) -> bytes:
+    """Canvas::write_to_file_simple (canvas.rs:86-109) into memory."""
+    a = np.ascontiguousarray(rgb, dtype=np.float64)
+    h, w = a.shape[0], a.shape[1]
+    p = a.ctypes.data_as(C.POINTER(C.c_double))
+    need = lib().rtc_canvas_format_ppm(p, w, h, None, 0)
+    buf = C.create_string_buffer(need + 1)
+    lib().rtc_canvas_format_ppm(p, w, h, buf, need + 1)
+    return buf.raw[:need]
+
+
+def write_ppm(path, rgb: np.ndarray) -> None:
+    a = np.ascontiguousarray(rgb, dtype=np.float64)
+    _check(lib().rtc_canvas_write_ppm(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[1], a.shape[0]), "Canvas.write_to_file_simple")
+
+
+# ---------------------------------------------------------------------------------------
+# device side
+# ---------------------------------------------------------------------------------------
+class Context:
+    """One GPU + one stream (rtc_context). `stream` is a raw hipStream_t value (int) or None."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = C.c_void_p()
+        _check(lib().rtc_context_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)), "rtc_context_create",
+               "no usable MI355X (gfx950); this library has no CPU fallback")
+        self.device = device
+
+    def close(self):
+        if self._h:
+            lib().rtc_context_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib().rtc_context_synchronize(self._h), "rtc_context_synchronize")
+
+    def device_info(self):
+        name = C.create_string_buffer(128)
+        cu, mhz = C.c_int32(), C.c_int32()
+        _check(lib().rtc_context_device_info(self._h, name, 128, C.byref(cu), C.byref(mhz)), "rtc_context_device_info")
+        return {"name": name.value.decode(), "compute_units": cu.value, "clock_mhz": mhz.value}
+
+    def upload(self, world: World) -> "DeviceWorld":
+        return DeviceWorld(self, world)
+
+    def stats(self) -> dict:
+        s = RtcStats()
+        _check(lib().rtc_stats_read(self._h, C.byref(s)), "rtc_stats_read")
+        return {"rays_primary": s.rays_primary, "rays_shadow": s.rays_shadow, "rays_reflect": s.rays_reflect,
+                "rays_refract": s.rays_refract, "pixels": s.pixels}
+
+    def reset_stats(self):
+        _check(lib().rtc_stats_reset(self._h), "rtc_stats_reset")
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float()
+        _check(lib().rtc_last_kernel_ms(self._h, C.byref(ms)), "rtc_last_kernel_ms")
+        return ms.value
+
+    def device_arith(self, op: int, a: np.ndarray, b: np.ndarray | None = None) -> np.ndarray:
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        bb = np.ascontiguousarray(b if b is not None else a, dtype=np.float64)
+        out = np.empty_like(a)
+        P = C.POINTER(C.c_double)
+        _check(lib().rtc_device_arith(self._h, op, a.ctypes.data_as(P), bb.ctypes.data_as(P), a.size, out.ctypes.data_as(P)), "rtc_device_arith")
+        return out
+
+
+class DeviceWorld:
+    """Flattened World resident in HBM (rtc_world)."""
+
+    def __init__(self, ctx: Context, world: World):
+        self.ctx = ctx
+        self._h = C.c_void_p()
+        arr = world.array()
+        _check(lib().rtc_world_create(ctx._h, arr, len(world.shapes), C.byref(world.light), C.byref(self._h)), "rtc_world_create")
+        self.n = len(world.shapes)
+
+    def close(self):
+        if self._h:
+            lib().rtc_world_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, cam: RtcCamera, mode: int = MODE_RENDER_ASYNC, flags: int = 0, with_stats: bool = False):
+        """Camera::render(&World) -> Canvas as a (vsize, hsize, 3) float64 array (host)."""
+        out = np.empty((cam.vsize, cam.hsize, 3), dtype=np.float64)
+        st = RtcStats()
+        _check(lib().rtc_render(self.ctx._h, self._h, C.byref(cam), mode, flags, out.ctypes.data_as(C.POINTER(C.c_double)),
+                                C.byref(st) if with_stats else None), "rtc_render")
+        if with_stats:
+            return out, {"rays_primary": st.rays_primary, "rays_shadow": st.rays_shadow, "rays_reflect": st.rays_reflect,
+                         "rays_refract": st.rays_refract, "pixels": st.pixels}
+        return out
+
+    def render_rows(self, cam: RtcCamera, y0: int, y1: int, d_ptr: int, mode: int = MODE_RENDER_ASYNC, flags: int = 0) -> None:
+        """Enqueue rows [y0, y1) into the DEVICE buffer at address `d_ptr` (no synchronisation)."""
+        _check(lib().rtc_render_rows(self.ctx._h, self._h, C.byref(cam), mode, y0, y1, C.c_void_p(d_ptr), flags), "rtc_render_rows")
+
+    def color_at(self, rays: np.ndarray, remaining: int = 5, want_hits: bool = False, flags: int = 0):
+        """World::color_at for an (n, 6) array of rays; returns rgb (n,3) [and the rtc_hit array]."""
+        r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)
+        n = r.shape[0]
+        rgb = np.empty((n, 3), dtype=np.float64)
+        hits = (RtcHit * max(1, n))() if want_hits else None
+        P = C.POINTER(C.c_double)
+        _check(lib().rtc_color_at(self.ctx._h, self._h, r.ctypes.data_as(P), n, remaining, flags, rgb.ctypes.data_as(P), hits), "rtc_color_at")
+        return (rgb, hits) if want_hits else rgb
+
+
+__all__ = ["lib", "RtcError", "Matrix", "material", "sphere", "plane", "cube", "light", "World", "camera", "ray_for_pixel",
+           "load_yaml", "format_ppm", "write_ppm", "Context", "DeviceWorld", "MODE_RENDER", "MODE_RENDER_ASYNC",
+           "SPHERE", "PLANE", "CUBE", "RtcCamera", "RtcHit", "RtcLight", "RtcMaterial", "RtcShape", "RtcStats"]

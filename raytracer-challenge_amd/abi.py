@@ -1,0 +1,104 @@
+"""ctypes mirror of include/rtc.h (struct layouts, constants, prototypes)."""
+from __future__ import annotations
+
+import ctypes as C
+
+Mat16 = C.c_double * 16
+Vec3 = C.c_double * 3
+
+SPHERE, PLANE, CUBE = 0, 1, 2
+MODE_RENDER, MODE_RENDER_ASYNC = 0, 1
+PATTERNS = {"none": 0, "test": 1, "stripe": 2, "stripes": 2, "gradient": 3, "ring": 4, "checker": 5, "checkers": 5, "grid": 6}
+STATUS_NAMES = {0: "RTC_OK", 1: "RTC_ERR_SINGULAR", 2: "RTC_ERR_NO_COLOR", 3: "RTC_ERR_DEVICE", 4: "RTC_ERR_ARG",
+                5: "RTC_ERR_PARSE", 6: "RTC_ERR_IO", 7: "RTC_ERR_NOMEM", 8: "RTC_ERR_UNSUPPORTED"}
+
+
+class RtcMaterial(C.Structure):
+    _fields_ = [("pattern_kind", C.c_uint32), ("has_color", C.c_uint32), ("color", Vec3),
+                ("ambient", C.c_double), ("diffuse", C.c_double), ("specular", C.c_double), ("shininess", C.c_double),
+                ("reflective", C.c_double), ("transparency", C.c_double), ("refractive_index", C.c_double),
+                ("pat_inv", Mat16), ("pat_a", Vec3), ("pat_b", Vec3)]
+
+
+class RtcShape(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("world_id", C.c_uint32), ("inv", Mat16), ("inv_t", Mat16), ("material", RtcMaterial)]
+
+
+class RtcLight(C.Structure):
+    _fields_ = [("intensity", Vec3), ("position", Vec3)]
+
+
+class RtcCamera(C.Structure):
+    _fields_ = [("hsize", C.c_uint32), ("vsize", C.c_uint32), ("fov", C.c_double), ("half_width", C.c_double),
+                ("half_height", C.c_double), ("pixel_size", C.c_double), ("view_inv", Mat16), ("samples", C.c_uint32),
+                ("_pad", C.c_uint32)]
+
+
+class RtcStats(C.Structure):
+    _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
+                ("rays_refract", C.c_uint64), ("pixels", C.c_uint64), ("_reserved", C.c_uint64 * 3)]
+
+
+class RtcHit(C.Structure):
+    _fields_ = [("hit_index", C.c_int32), ("inside", C.c_uint32), ("shadowed", C.c_uint32), ("_pad", C.c_uint32),
+                ("t", C.c_double), ("point", Vec3), ("over_point", Vec3), ("under_point", Vec3), ("eyev", Vec3),
+                ("normal", Vec3), ("reflectv", Vec3), ("n1", C.c_double), ("n2", C.c_double)]
+
+
+assert C.sizeof(RtcMaterial) == 264 and C.sizeof(RtcShape) == 528 and C.sizeof(RtcHit) == 184
+
+D = C.c_double
+PD = C.POINTER(C.c_double)
+U32 = C.c_uint32
+VP = C.c_void_p
+
+# name -> (restype, argtypes); every symbol include/rtc.h declares
+PROTOTYPES = {
+    "rtc_abi_version": (U32, []),
+    "rtc_strerror": (C.c_char_p, [C.c_int32]),
+    "rtc_matrix_identity": (None, [Mat16]),
+    "rtc_matrix_multiply": (None, [Mat16, Mat16, Mat16]),
+    "rtc_matrix_translation": (None, [Mat16, D, D, D, Mat16]),
+    "rtc_matrix_scaling": (None, [Mat16, D, D, D, Mat16]),
+    "rtc_matrix_rotation_x": (None, [Mat16, D, Mat16]),
+    "rtc_matrix_rotation_y": (None, [Mat16, D, Mat16]),
+    "rtc_matrix_rotation_z": (None, [Mat16, D, Mat16]),
+    "rtc_matrix_shearing": (None, [Mat16, D, D, D, D, D, D, Mat16]),
+    "rtc_matrix_determinant": (D, [Mat16]),
+    "rtc_matrix_inverse": (C.c_int32, [Mat16, Mat16]),
+    "rtc_matrix_transpose": (None, [Mat16, Mat16]),
+    "rtc_view_transform": (None, [Vec3, Vec3, Vec3, Mat16]),
+    "rtc_camera_init": (C.c_int32, [U32, U32, D, Mat16, C.POINTER(RtcCamera)]),
+    "rtc_camera_ray_for_pixel": (None, [C.POINTER(RtcCamera), U32, D, U32, D, C.c_double * 6]),
+    "rtc_material_default": (None, [C.POINTER(RtcMaterial)]),
+    "rtc_shape_init": (C.c_int32, [U32, Mat16, C.POINTER(RtcMaterial), C.POINTER(RtcShape)]),
+    "rtc_material_set_pattern": (C.c_int32, [C.POINTER(RtcMaterial), U32, Vec3, Vec3, Mat16]),
+    "rtc_light_default": (None, [C.POINTER(RtcLight)]),
+    "rtc_scene_load_yaml": (C.c_int32, [C.c_char_p, C.POINTER(C.POINTER(RtcShape)), C.POINTER(U32), C.POINTER(RtcLight),
+                                        C.POINTER(RtcCamera), C.c_char_p, C.c_size_t]),
+    "rtc_scene_load_yaml_file": (C.c_int32, [C.c_char_p, C.POINTER(C.POINTER(RtcShape)), C.POINTER(U32), C.POINTER(RtcLight),
+                                             C.POINTER(RtcCamera), C.c_char_p, C.c_size_t]),
+    "rtc_free": (None, [VP]),
+    "rtc_canvas_write_ppm": (C.c_int32, [C.c_char_p, PD, U32, U32]),
+    "rtc_canvas_format_ppm": (C.c_size_t, [PD, U32, U32, C.c_char_p, C.c_size_t]),
+    "rtc_context_create": (C.c_int32, [C.c_int32, VP, C.POINTER(VP)]),
+    "rtc_context_destroy": (None, [VP]),
+    "rtc_context_synchronize": (C.c_int32, [VP]),
+    "rtc_context_device_info": (C.c_int32, [VP, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "rtc_world_create": (C.c_int32, [VP, C.POINTER(RtcShape), U32, C.POINTER(RtcLight), C.POINTER(VP)]),
+    "rtc_world_destroy": (None, [VP]),
+    "rtc_render_rows": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, U32, VP, U32]),
+    "rtc_render": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, PD, C.POINTER(RtcStats)]),
+    "rtc_stats_read": (C.c_int32, [VP, C.POINTER(RtcStats)]),
+    "rtc_stats_reset": (C.c_int32, [VP]),
+    "rtc_last_kernel_ms": (C.c_int32, [VP, C.POINTER(C.c_float)]),
+    "rtc_color_at": (C.c_int32, [VP, VP, PD, U32, U32, U32, PD, C.POINTER(RtcHit)]),
+    "rtc_device_arith": (C.c_int32, [VP, U32, PD, PD, U32, PD]),
+}
+
+
+def declare(lib: C.CDLL) -> None:
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args

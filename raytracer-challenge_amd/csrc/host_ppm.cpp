@@ -1,0 +1,79 @@
+// host_ppm.cpp — [host] Canvas::write_to_file_simple (ch1/src/canvas.rs:86-109): ASCII PPM "P3",
+// one text line per canvas row, components separated by single spaces, no 70-column
+// wrapping, each component quantised by Color::scale (ch1/src/color.rs:100-114).
+#include "rtc.h"
+
+#include <cstdio>
+#include <string>
+
+namespace {
+
+// Color::scale(component, 255): `(component * 255.0) as i32` is Rust's truncating,
+// saturating float->int cast (NaN -> 0), then clamp to [0, scale].
+int scale255(double component) {
+    const double v = component * 255.0;
+    long long q;
+    if (v != v) q = 0;
+    else if (v >= 2147483647.0) q = 2147483647LL;
+    else if (v <= -2147483648.0) q = -2147483648LL;
+    else q = static_cast<long long>(v); // truncates toward zero
+    if (q < 0) return 0;
+    if (q > 255) return 255;
+    return static_cast<int>(q);
+}
+
+void append_uint(std::string &s, unsigned v) {
+    char tmp[16];
+    int n = 0;
+    do { tmp[n++] = static_cast<char>('0' + v % 10); v /= 10; } while (v);
+    while (n) s.push_back(tmp[--n]);
+}
+
+std::string encode(const double *rgb, uint32_t width, uint32_t height) {
+    std::string s;
+    s.reserve(static_cast<size_t>(width) * height * 12 + 32);
+    s += "P3\n";
+    append_uint(s, width);
+    s.push_back(' ');
+    append_uint(s, height);
+    s += "\n255\n";
+    for (uint32_t row = 0; row < height; ++row) {
+        const double *line = rgb + static_cast<size_t>(row) * width * 3;
+        for (uint32_t col = 0; col < width; ++col) {
+            if (col) s.push_back(' ');
+            for (int ch = 0; ch < 3; ++ch) {
+                if (ch) s.push_back(' ');
+                append_uint(s, static_cast<unsigned>(scale255(line[col * 3 + ch])));
+            }
+        }
+        s.push_back('\n');
+    }
+    return s;
+}
+
+} // namespace
+
+extern "C" {
+
+size_t rtc_canvas_format_ppm(const double *rgb, uint32_t width, uint32_t height, char *buf, size_t cap) {
+    if (!rgb) return 0;
+    const std::string s = encode(rgb, width, height);
+    if (buf && cap) {
+        const size_t n = s.size() < cap ? s.size() : cap;
+        s.copy(buf, n);
+        if (n < cap) buf[n] = 0;
+    }
+    return s.size();
+}
+
+rtc_status rtc_canvas_write_ppm(const char *path, const double *rgb, uint32_t width, uint32_t height) {
+    if (!path || !rgb) return RTC_ERR_ARG;
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) return RTC_ERR_IO; // reference: panic!("Could not open output file ...") canvas.rs:87-91
+    const std::string s = encode(rgb, width, height);
+    const size_t w = std::fwrite(s.data(), 1, s.size(), f);
+    const int c = std::fclose(f);
+    return (w == s.size() && c == 0) ? RTC_OK : RTC_ERR_IO;
+}
+
+} // extern "C"

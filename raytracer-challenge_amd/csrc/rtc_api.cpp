@@ -1,0 +1,407 @@
+// rtc_api.cpp — [device] half of the C-ABI in include/rtc.h: context, HBM-resident World,
+// render / color_at launches. Compiled by hipcc together with rtc_kernels.hip.
+//
+// There is deliberately no CPU fallback here: without a usable gfx950 device every entry
+// point returns RTC_ERR_DEVICE.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "rtc.h"
+#include "rtc_device.h"
+
+extern "C" hipError_t rtc_launch_trace(const RenderParams *P, int src, int refl, int refr, uint32_t nblocks,
+                                       size_t lds_bytes, hipStream_t stream);
+extern "C" hipError_t rtc_launch_prep(const DevIsect *isect, DevPrim *prim, uint32_t n, const double vinv[12],
+                                      hipStream_t stream);
+extern "C" hipError_t rtc_launch_arith(uint32_t op, const double *a, const double *b, uint32_t n, double *out,
+                                       hipStream_t stream);
+
+enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2 };
+
+struct rtc_context {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool owns_stream = false;
+    unsigned long long *d_counters = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool have_timing = false;
+    int force_src = -1;   // RTC_SRC env override (experiments)
+    uint32_t tile_cap = 512;
+};
+
+struct rtc_world {
+    rtc_context *ctx = nullptr;
+    uint32_t n = 0;
+    DevIsect *d_isect = nullptr;
+    uint32_t *d_kind = nullptr;
+    DevShade *d_shade = nullptr;
+    DevPrim *d_prim = nullptr;
+    DevBound *d_bound = nullptr;
+    rtc_light light{};
+    bool any_refl = false, any_refr = false;
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                   \
+    do {                                                \
+        if ((expr) != hipSuccess) return RTC_ERR_DEVICE; \
+    } while (0)
+
+struct DeviceGuard { // make ctx->device current for the calling thread
+    explicit DeviceGuard(int dev) { ok = hipSetDevice(dev) == hipSuccess; }
+    bool ok;
+};
+
+void choose_source(const rtc_context *ctx, uint32_t n, int *src, uint32_t *tile_cap, size_t *lds_bytes) {
+    // per object in LDS: 96 B inverse rows + 32 B primary prologue + 4 B kind
+    const uint32_t per_obj = 96 + 32 + 4;
+    int s;
+    if (ctx->force_src >= 0) s = ctx->force_src;
+    else if (n <= 128) s = SRC_SMEM;
+    else if (n <= 448) s = SRC_LDS1;
+    else s = SRC_LDSN;
+    uint32_t cap = 0;
+    if (s == SRC_LDS1) {
+        if ((size_t)n * per_obj > 150 * 1024) s = SRC_LDSN;
+        else cap = n ? n : 1;
+    }
+    if (s == SRC_LDSN) cap = ctx->tile_cap;
+    if (s == SRC_SMEM) cap = 0;
+    *src = s;
+    *tile_cap = cap;
+    // kinds sit behind cap*16 doubles; round the block up to 16 bytes
+    *lds_bytes = cap ? (((size_t)cap * per_obj + 15) & ~(size_t)15) : 0;
+}
+
+void fill_camera(RenderParams &P, const rtc_camera *cam) {
+    P.W = cam->hsize;
+    P.H = cam->vsize;
+    P.samples = cam->samples ? cam->samples : 1;
+    P.half_width = cam->half_width;
+    P.half_height = cam->half_height;
+    P.pixel_size = cam->pixel_size;
+    std::memcpy(P.vinv, cam->view_inv, sizeof(double) * 12);
+}
+
+void fill_world(RenderParams &P, const rtc_world *w) {
+    P.isect = w->d_isect;
+    P.kind = w->d_kind;
+    P.shade = w->d_shade;
+    P.prim = w->d_prim;
+    P.bound = w->d_bound;
+    P.n = w->n;
+    for (int i = 0; i < 3; ++i) {
+        P.light_pos[i] = w->light.position[i];
+        P.light_int[i] = w->light.intensity[i];
+    }
+}
+
+} // namespace
+
+extern "C" {
+
+rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
+    if (!out) return RTC_ERR_ARG;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0 || device < 0 || device >= count) return RTC_ERR_DEVICE;
+    HIP_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) return RTC_ERR_DEVICE; // kernels are gfx950-only
+    rtc_context *ctx = new (std::nothrow) rtc_context;
+    if (!ctx) return RTC_ERR_NOMEM;
+    ctx->device = device;
+    if (stream) {
+        ctx->stream = static_cast<hipStream_t>(stream);
+    } else {
+        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return RTC_ERR_DEVICE; }
+        ctx->owns_stream = true;
+    }
+    if (hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * CNT_N) != hipSuccess ||
+        hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        rtc_context_destroy(ctx);
+        return RTC_ERR_DEVICE;
+    }
+    if (const char *e = std::getenv("RTC_SRC")) {
+        const int v = std::atoi(e);
+        if (v >= 0 && v <= 2) ctx->force_src = v;
+    }
+    if (const char *e = std::getenv("RTC_TILE_CAP")) {
+        const int v = std::atoi(e);
+        if (v >= 16 && v <= 1024) ctx->tile_cap = (uint32_t)v;
+    }
+    *out = ctx;
+    return RTC_OK;
+}
+
+void rtc_context_destroy(rtc_context *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+rtc_status rtc_context_synchronize(rtc_context *ctx) {
+    if (!ctx) return RTC_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RTC_OK;
+}
+
+rtc_status rtc_context_device_info(rtc_context *ctx, char *name, size_t cap, int32_t *compute_units, int32_t *clock_mhz) {
+    if (!ctx) return RTC_ERR_ARG;
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, ctx->device));
+    if (name && cap) {
+        std::strncpy(name, prop.name, cap - 1);
+        name[cap - 1] = 0;
+    }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (clock_mhz) *clock_mhz = prop.clockRate / 1000;
+    return RTC_OK;
+}
+
+rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t n, const rtc_light *light, rtc_world **out) {
+    if (!ctx || !out || !light || (n && !shapes)) return RTC_ERR_ARG;
+    *out = nullptr;
+    // Material::lighting panics when a material has neither colour nor pattern (material.rs:328-331)
+    for (uint32_t i = 0; i < n; ++i) {
+        if (shapes[i].kind > RTC_CUBE || shapes[i].material.pattern_kind > RTC_PATTERN_GRID) return RTC_ERR_ARG;
+        if (shapes[i].material.pattern_kind == RTC_PATTERN_NONE && !shapes[i].material.has_color) return RTC_ERR_NO_COLOR;
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint32_t na = n ? n : 1;
+    std::vector<DevIsect> isect(na);
+    std::vector<uint32_t> kind(na, 0);
+    std::vector<DevShade> shade(na);
+    std::vector<DevBound> bound(na);
+    std::memset(isect.data(), 0, sizeof(DevIsect) * na);
+    std::memset(shade.data(), 0, sizeof(DevShade) * na);
+    bool any_refl = false, any_refr = false;
+    for (uint32_t i = 0; i < n; ++i) {
+        const rtc_shape &s = shapes[i];
+        const rtc_material &m = s.material;
+        std::memcpy(isect[i].m, s.inv, sizeof(double) * 12);
+        kind[i] = s.kind;
+        DevShade &d = shade[i];
+        for (int r = 0; r < 3; ++r)
+            for (int c = 0; c < 3; ++c)
+                // Shape::normal_at uses transform_transpose (shape.rs:38); Cube::normal_at
+                // transposes its inverse on the fly (shape.rs:627)
+                d.nt[r * 3 + c] = (s.kind == RTC_CUBE) ? s.inv[c * 4 + r] : s.inv_t[r * 4 + c];
+        for (int c = 0; c < 3; ++c) {
+            d.color[c] = m.color[c];
+            d.pat_a[c] = m.pat_a[c];
+            d.pat_b[c] = m.pat_b[c];
+        }
+        d.ambient = m.ambient;
+        d.diffuse = m.diffuse;
+        d.specular = m.specular;
+        d.shininess = m.shininess;
+        d.reflective = m.reflective;
+        d.transparency = m.transparency;
+        d.refractive_index = m.refractive_index;
+        std::memcpy(d.pat_inv, m.pat_inv, sizeof(double) * 12);
+        d.kind = s.kind;
+        d.pattern_kind = m.pattern_kind;
+        d.world_id = s.world_id;
+        if (m.reflective > 0.) any_refl = true;     // reflected_color shape.rs:730
+        if (m.transparency != 0.0) any_refr = true; // refracted_color shape.rs:752
+        bound[i] = DevBound{0.f, 0.f, 0.f, INFINITY};
+    }
+    rtc_world *w = new (std::nothrow) rtc_world;
+    if (!w) return RTC_ERR_NOMEM;
+    w->ctx = ctx;
+    w->n = n;
+    w->light = *light;
+    w->any_refl = any_refl;
+    w->any_refr = any_refr;
+    bool ok = hipMalloc(&w->d_isect, sizeof(DevIsect) * na) == hipSuccess &&
+              hipMalloc(&w->d_kind, sizeof(uint32_t) * na) == hipSuccess &&
+              hipMalloc(&w->d_shade, sizeof(DevShade) * na) == hipSuccess &&
+              hipMalloc(&w->d_prim, sizeof(DevPrim) * na) == hipSuccess &&
+              hipMalloc(&w->d_bound, sizeof(DevBound) * na) == hipSuccess;
+    ok = ok && hipMemcpy(w->d_isect, isect.data(), sizeof(DevIsect) * na, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(w->d_kind, kind.data(), sizeof(uint32_t) * na, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(w->d_shade, shade.data(), sizeof(DevShade) * na, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(w->d_bound, bound.data(), sizeof(DevBound) * na, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemset(w->d_prim, 0, sizeof(DevPrim) * na) == hipSuccess;
+    if (!ok) {
+        rtc_world_destroy(w);
+        return RTC_ERR_DEVICE;
+    }
+    *out = w;
+    return RTC_OK;
+}
+
+void rtc_world_destroy(rtc_world *w) {
+    if (!w) return;
+    if (w->ctx) {
+        (void)hipSetDevice(w->ctx->device);
+        (void)hipStreamSynchronize(w->ctx->stream);
+    }
+    if (w->d_isect) (void)hipFree(w->d_isect);
+    if (w->d_kind) (void)hipFree(w->d_kind);
+    if (w->d_shade) (void)hipFree(w->d_shade);
+    if (w->d_prim) (void)hipFree(w->d_prim);
+    if (w->d_bound) (void)hipFree(w->d_bound);
+    delete w;
+}
+
+rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode, uint32_t y0,
+                           uint32_t y1, void *d_rgb, uint32_t flags) {
+    if (!ctx || !w || !cam || !d_rgb || w->ctx != ctx) return RTC_ERR_ARG;
+    if (mode > RTC_MODE_RENDER_ASYNC || cam->hsize == 0 || cam->vsize == 0 || y0 > y1 || y1 > cam->vsize) return RTC_ERR_ARG;
+    (void)flags;
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (y0 == y1) return RTC_OK;
+    RenderParams P;
+    std::memset(&P, 0, sizeof P);
+    fill_world(P, w);
+    fill_camera(P, cam);
+    P.y0 = y0;
+    P.y1 = y1;
+    P.mode = mode;
+    P.out = static_cast<double *>(d_rgb);
+    P.counters = ctx->d_counters;
+    P.rays = nullptr;
+    P.remaining = RTC_MAX_REFLECTIONS; // render_pixel passes Camera::MAX_REFLECTIONS camera.rs:98
+    P.grid_x = (cam->hsize + 31u) / 32u;
+    P.grid_y = (y1 - y0 + 7u) / 8u;
+    int src;
+    size_t lds_bytes;
+    choose_source(ctx, w->n, &src, &P.tile_cap, &lds_bytes);
+    HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.vinv, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y, lds_bytes, ctx->stream));
+    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
+    ctx->have_timing = true;
+    return RTC_OK;
+}
+
+rtc_status rtc_stats_read(rtc_context *ctx, rtc_stats *out) {
+    if (!ctx || !out) return RTC_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    unsigned long long h[CNT_N];
+    HIP_TRY(hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    std::memset(out, 0, sizeof *out);
+    out->rays_primary = h[CNT_PRIMARY];
+    out->rays_shadow = h[CNT_SHADOW];
+    out->rays_reflect = h[CNT_REFLECT];
+    out->rays_refract = h[CNT_REFRACT];
+    out->pixels = h[CNT_PIXELS];
+    return RTC_OK;
+}
+
+rtc_status rtc_stats_reset(rtc_context *ctx) {
+    if (!ctx) return RTC_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+    return RTC_OK;
+}
+
+rtc_status rtc_last_kernel_ms(rtc_context *ctx, float *ms) {
+    if (!ctx || !ms || !ctx->have_timing) return RTC_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipEventSynchronize(ctx->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    return RTC_OK;
+}
+
+rtc_status rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode, uint32_t flags,
+                      double *rgb, rtc_stats *stats) {
+    if (!ctx || !w || !cam || !rgb) return RTC_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = sizeof(double) * 3 * (size_t)cam->hsize * cam->vsize;
+    if (bytes == 0) return RTC_ERR_ARG;
+    double *d = nullptr;
+    HIP_TRY(hipMalloc(&d, bytes));
+    rtc_status st = RTC_OK;
+    if (stats) st = rtc_stats_reset(ctx);
+    if (st == RTC_OK) st = rtc_render_rows(ctx, w, cam, mode, 0, cam->vsize, d, flags);
+    if (st == RTC_OK && hipMemcpyAsync(rgb, d, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
+    if (st == RTC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
+    if (st == RTC_OK && stats) st = rtc_stats_read(ctx, stats);
+    (void)hipFree(d);
+    return st;
+}
+
+rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays, uint32_t n, uint32_t remaining,
+                        uint32_t flags, double *rgb, rtc_hit *hits) {
+    if (!ctx || !w || !rays || !rgb || w->ctx != ctx) return RTC_ERR_ARG;
+    if (remaining > 7) return RTC_ERR_ARG; // frame stack depth of the kernel (reference uses <= 5)
+    (void)flags;
+    if (n == 0) return RTC_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    double *d_rays = nullptr, *d_rgb = nullptr;
+    rtc_hit *d_hits = nullptr;
+    rtc_status st = RTC_OK;
+    if (hipMalloc(&d_rays, sizeof(double) * 6 * n) != hipSuccess || hipMalloc(&d_rgb, sizeof(double) * 3 * n) != hipSuccess ||
+        (hits && hipMalloc(&d_hits, sizeof(rtc_hit) * n) != hipSuccess))
+        st = RTC_ERR_DEVICE;
+    if (st == RTC_OK && hipMemcpyAsync(d_rays, rays, sizeof(double) * 6 * n, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        st = RTC_ERR_DEVICE;
+    if (st == RTC_OK) {
+        RenderParams P;
+        std::memset(&P, 0, sizeof P);
+        fill_world(P, w);
+        P.W = n; P.H = 1; P.y0 = 0; P.y1 = 1; P.mode = RTC_MODE_RENDER_ASYNC; P.samples = 1;
+        P.out = d_rgb;
+        P.counters = nullptr;
+        P.rays = d_rays;
+        P.nrays = n;
+        P.remaining = remaining;
+        P.hits = d_hits;
+        P.grid_x = (n + 255u) / 256u;
+        P.grid_y = 1;
+        int src;
+        size_t lds_bytes;
+        choose_source(ctx, w->n, &src, &P.tile_cap, &lds_bytes);
+        if (rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x, lds_bytes, ctx->stream) != hipSuccess)
+            st = RTC_ERR_DEVICE;
+    }
+    if (st == RTC_OK && hipMemcpyAsync(rgb, d_rgb, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        st = RTC_ERR_DEVICE;
+    if (st == RTC_OK && hits && hipMemcpyAsync(hits, d_hits, sizeof(rtc_hit) * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        st = RTC_ERR_DEVICE;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
+    if (d_rays) (void)hipFree(d_rays);
+    if (d_rgb) (void)hipFree(d_rgb);
+    if (d_hits) (void)hipFree(d_hits);
+    return st;
+}
+
+rtc_status rtc_device_arith(rtc_context *ctx, uint32_t op, const double *a, const double *b, uint32_t n, double *out) {
+    if (!ctx || !a || !out || op > 4 || (op == 1 && !b) || (op == 2 && !b)) return RTC_ERR_ARG;
+    if (n == 0) return RTC_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    double *da = nullptr, *db = nullptr, *dout = nullptr;
+    rtc_status st = RTC_OK;
+    const size_t bytes = sizeof(double) * n;
+    if (hipMalloc(&da, bytes) != hipSuccess || hipMalloc(&db, bytes) != hipSuccess || hipMalloc(&dout, bytes) != hipSuccess)
+        st = RTC_ERR_DEVICE;
+    if (st == RTC_OK && hipMemcpy(da, a, bytes, hipMemcpyHostToDevice) != hipSuccess) st = RTC_ERR_DEVICE;
+    if (st == RTC_OK && hipMemcpy(db, b ? b : a, bytes, hipMemcpyHostToDevice) != hipSuccess) st = RTC_ERR_DEVICE;
+    if (st == RTC_OK && rtc_launch_arith(op, da, db, n, dout, ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
+    if (st == RTC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
+    if (st == RTC_OK && hipMemcpy(out, dout, bytes, hipMemcpyDeviceToHost) != hipSuccess) st = RTC_ERR_DEVICE;
+    if (da) (void)hipFree(da);
+    if (db) (void)hipFree(db);
+    if (dout) (void)hipFree(dout);
+    return st;
+}
+
+} // extern "C"

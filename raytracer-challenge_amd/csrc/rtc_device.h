@@ -1,0 +1,66 @@
+// rtc_device.h — layout of the flattened World in HBM and the kernel parameter block.
+// Shared by rtc_api.cpp (host side of the C-ABI) and rtc_kernels.hip.
+//
+// HBM layout (all f64, written once per rtc_world_create, read-only afterwards):
+//   isect[n]  96 B  rows 0..2 of the shape's stored inverse transform — everything
+//                   Shape::intersect needs (vec.rs:211-214, transform.rs:107-128);
+//                   read wave-uniformly through the scalar cache (or staged in LDS tiles).
+//   kind[n]    4 B  RTC_SPHERE / RTC_PLANE / RTC_CUBE.
+//   bound[n]  16 B  f32 world-space bounding sphere (centre, radius) for the conservative cull.
+//   shade[n] 320 B  what shade_hit needs for the ONE object a ray hit: inverse-transpose 3x3,
+//                   material scalars, pattern; gathered per lane after the hit is known.
+//   prim[n]   32 B  per-render scratch: the camera origin in object space and `c` of the sphere
+//                   quadratic — identical for every primary ray, so computed once per object
+//                   (with the reference's arithmetic) instead of once per pixel x object.
+#ifndef RTC_DEVICE_H
+#define RTC_DEVICE_H
+
+#include <stdint.h>
+
+struct DevIsect {
+    double m[12]; // inv[0][0..3], inv[1][0..3], inv[2][0..3]
+};
+
+struct DevShade {
+    double nt[9];       // 3x3 of transform_transpose (shape.rs:285,301); cubes use inv^T (shape.rs:627)
+    double color[3];
+    double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
+    double pat_inv[12]; // rows 0..2 of Pattern.xf_inv
+    double pat_a[3], pat_b[3];
+    uint32_t kind, pattern_kind, world_id, _pad;
+};
+
+struct DevPrim {
+    double ox, oy, oz; // transform_point(inv, camera origin)
+    double c;          // (o.o) - 1.   (shape.rs:366)
+};
+
+struct DevBound {
+    float cx, cy, cz, r; // r = +inf: unbounded (planes) or not computable -> never culled
+};
+
+enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PIXELS = 4, CNT_N = 8 };
+
+struct RenderParams {
+    const DevIsect *isect;
+    const uint32_t *kind;
+    const DevShade *shade;
+    const DevPrim *prim;
+    const DevBound *bound;
+    uint32_t n;
+    uint32_t tile_cap; // objects per LDS tile (LDS variants)
+    double light_pos[3], light_int[3];
+    // camera (camera.rs:17-27)
+    uint32_t W, H, y0, y1, mode, samples;
+    double half_width, half_height, pixel_size;
+    double vinv[12];
+    double *out;                 // (y1-y0) x W x 3
+    unsigned long long *counters; // CNT_N
+    // probe mode (rtc_color_at): rays != nullptr
+    const double *rays;
+    uint32_t nrays, remaining;
+    void *hits; // rtc_hit[nrays] or nullptr
+    uint32_t grid_x, grid_y; // logical block grid of the render (for the XCD-aware remap)
+};
+
+#endif

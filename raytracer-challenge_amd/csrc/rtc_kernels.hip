@@ -1,0 +1,721 @@
+// rtc_kernels.hip — hand-written CDNA4 (gfx950, wave64) kernels for the hot path
+//   Camera::render -> World::color_at -> World::intersect -> shade_hit
+// of joedane/raytracer-challenge (ch1/src/camera.rs:94-160, shape.rs:677-781,
+// material.rs:319-361).
+//
+// Design:
+//  * one thread per pixel; a wave owns an 8x8 pixel tile (coherent hit / miss / shadow
+//    decisions), a 256-thread workgroup a 32x8 tile; blockIdx is remapped so that the
+//    workgroups of one XCD cover a contiguous band of the image.
+//  * every value is IEEE f64 evaluated in the reference's operation order; the file is
+//    compiled with -ffp-contract=off, so results are bit-identical to the CPU path apart
+//    from pow() (material.rs:355).
+//  * the object loop is wave-uniform: records come either through the scalar cache into
+//    SGPRs (SRC_SMEM, small worlds) or from LDS tiles shared by the workgroup (SRC_LDS1 one
+//    tile, SRC_LDSN many tiles with a barrier per tile, for worlds that exceed LDS).
+//  * the sorted Intersections list of the reference (shape.rs:167-237) is replaced by its
+//    streaming equivalent: running minimum over t >= 0 with first-inserted-wins ties
+//    (closest hit), any-hit with early exit (shadow), and an "open set" pass for n1/n2
+//    (compute_refractive, shape.rs:115-141) taken only when the hit material is transparent.
+//  * recursion (reflected_color / refracted_color, depth <= 5) is an explicit per-thread
+//    frame stack; colours are folded back in the reference's nesting order.
+//  * no MFMA anywhere: there is no dense contraction on this path.
+#include <hip/hip_runtime.h>
+
+#include "rtc.h"
+#include "rtc_device.h"
+
+#define RTC_BLOCK 256
+#define RTC_MAX_STACK 8
+
+enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2 };
+
+struct V3 {
+    double x, y, z;
+};
+
+#define DEVI __device__ __forceinline__
+
+DEVI V3 mk(double x, double y, double z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
+DEVI V3 vadd(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
+DEVI V3 vsub(V3 a, V3 b) { return mk(a.x - b.x, a.y - b.y, a.z - b.z); }
+DEVI V3 vmul(V3 a, double m) { return mk(a.x * m, a.y * m, a.z * m); }
+DEVI V3 vmulv(V3 a, V3 b) { return mk(a.x * b.x, a.y * b.y, a.z * b.z); }
+DEVI V3 vneg(V3 a) { return mk(-a.x, -a.y, -a.z); }
+// Vector::dot vec.rs:78-82: (x*x' + y*y') + z*z'
+DEVI double vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+// Vector::normalize vec.rs:65-76: magnitude, then three divisions
+DEVI V3 vnormalize(V3 a) {
+    const double mag = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    return mk(a.x / mag, a.y / mag, a.z / mag);
+}
+// Vector::reflect vec.rs:106-108: self - n*(2*(self.n))
+DEVI V3 vreflect(V3 v, V3 n) { return vsub(v, vmul(n, 2. * vdot(v, n))); }
+
+// Matrix::transform_point transform.rs:122-128 (rows of 4, row 3 never read)
+template <class P> DEVI V3 xpoint(P m, V3 p) {
+    return mk(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3], m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7],
+              m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11]);
+}
+// Matrix::transform_vector transform.rs:107-120
+template <class P> DEVI V3 xvector(P m, V3 v) {
+    return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z,
+              m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+// transform_vector with a packed 3x3
+DEVI V3 xvector3(const double *m, V3 v) {
+    return mk(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[3] * v.x + m[4] * v.y + m[5] * v.z,
+              m[6] * v.x + m[7] * v.y + m[8] * v.z);
+}
+
+DEVI unsigned long long ballot(bool p) { return __ballot(p ? 1 : 0); }
+DEVI uint32_t popc64(unsigned long long m) { return (uint32_t)__popcll(m); }
+
+// Cube::check_axis shape.rs:540-564
+DEVI void check_axis(double origin, double direction, double &tmin, double &tmax) {
+    const double tmin_numerator = -1.0 - origin;
+    const double tmax_numerator = 1. - origin;
+    if (fabs(direction) >= RTC_EPSILON) {
+        tmin = tmin_numerator / direction;
+        tmax = tmax_numerator / direction;
+    } else {
+        tmin = (tmin_numerator >= 0.0) ? __builtin_inf() : -__builtin_inf();
+        tmax = (tmax_numerator >= 0.0) ? __builtin_inf() : -__builtin_inf();
+    }
+    if (tmin > tmax) {
+        const double s = tmin;
+        tmin = tmax;
+        tmax = s;
+    }
+}
+
+// Entries of one shape for a ray already in object space, in the order the reference's
+// per-shape list holds them (shape.rs:361-375, 462-471, 577-591). Returns their count.
+// `c_pre`: the sphere's `c` when the caller already has it (primary rays).
+template <bool HAVE_C> DEVI int shape_entries(uint32_t kind, V3 o, V3 d, double c_pre, double &t0, double &t1) {
+    if (kind == RTC_SPHERE) {
+        const double a = vdot(d, d);
+        const double b = 2. * vdot(d, o);
+        const double c = HAVE_C ? c_pre : (vdot(o, o) - 1.);
+        const double disc = (b * b) - 4. * a * c;
+        if (disc < 0.) return 0;
+        const double sq = sqrt(disc);
+        const double den = 2. * a;
+        t0 = (-b - sq) / den;
+        t1 = (-b + sq) / den;
+        return 2;
+    } else if (kind == RTC_PLANE) {
+        if (fabs(d.y) < RTC_EPSILON) return 0;
+        t0 = -o.y / d.y;
+        return 1;
+    } else {
+        double xmin, xmax, ymin, ymax, zmin, zmax;
+        check_axis(o.x, d.x, xmin, xmax);
+        check_axis(o.y, d.y, ymin, ymax);
+        check_axis(o.z, d.z, zmin, zmax);
+        const double tmin = fmax(xmin, fmax(ymin, zmin));
+        const double tmax = fmin(xmax, fmin(ymax, zmax));
+        if (tmin < tmax) {
+            t0 = tmin;
+            t1 = tmax;
+            return 2;
+        }
+        return 0;
+    }
+}
+
+// Closest-hit update for one object: Intersections::get_hit (shape.rs:220-232) over the merged
+// sorted list == smallest t >= 0.0, ties to the entry inserted first (lower object index, then
+// first root). For a sphere t1 <= t2, so the second root is only needed when the first is not
+// a candidate (t1 < 0 or NaN).
+template <bool HAVE_C>
+DEVI void closest_update(uint32_t kind, V3 o, V3 d, double c_pre, int j, double &best, int &hidx, int &hroot) {
+    if (kind == RTC_SPHERE) {
+        const double a = vdot(d, d);
+        const double b = 2. * vdot(d, o);
+        const double c = HAVE_C ? c_pre : (vdot(o, o) - 1.);
+        const double disc = (b * b) - 4. * a * c;
+        if (!(disc < 0.)) {
+            const double sq = sqrt(disc);
+            const double den = 2. * a;
+            const double t1 = (-b - sq) / den;
+            if (t1 >= 0.0) {
+                if (t1 < best) { best = t1; hidx = j; hroot = 0; }
+            } else {
+                const double t2 = (-b + sq) / den;
+                if (t2 >= 0.0 && t2 < best) { best = t2; hidx = j; hroot = 1; }
+            }
+        }
+    } else {
+        double t0 = 0., t1 = 0.;
+        const int cnt = shape_entries<false>(kind, o, d, 0., t0, t1);
+        if (cnt >= 1 && t0 >= 0.0 && t0 < best) { best = t0; hidx = j; hroot = 0; }
+        if (cnt == 2 && t1 >= 0.0 && t1 < best) { best = t1; hidx = j; hroot = 1; }
+    }
+}
+
+// is_shadowed_by_light (shape.rs:716-727): hit.t < distance  <=>  some entry has 0 <= t < distance.
+DEVI bool occludes(uint32_t kind, V3 o, V3 d, double dist) {
+    if (kind == RTC_SPHERE) {
+        const double a = vdot(d, d);
+        const double b = 2. * vdot(d, o);
+        const double c = vdot(o, o) - 1.;
+        const double disc = (b * b) - 4. * a * c;
+        if (disc < 0.) return false;
+        const double sq = sqrt(disc);
+        const double den = 2. * a;
+        const double t1 = (-b - sq) / den;
+        if (t1 >= 0.0) return t1 < dist;
+        const double t2 = (-b + sq) / den;
+        return t2 >= 0.0 && t2 < dist;
+    }
+    double t0 = 0., t1 = 0.;
+    const int cnt = shape_entries<false>(kind, o, d, 0., t0, t1);
+    if (cnt >= 1 && t0 >= 0.0 && t0 < dist) return true;
+    if (cnt == 2 && t1 >= 0.0 && t1 < dist) return true;
+    return false;
+}
+
+// ---- wave-uniform object loop ------------------------------------------------------------
+// f(j, m, kind, prim) is called for objects j = 0..n-1 in insertion order (World::intersect,
+// shape.rs:679-681) and returns true while some lane of the wave still needs objects.
+// SRC_SMEM : uniform global loads (scalar cache -> SGPR operands); no barriers.
+// SRC_LDS1 : the whole table was staged into LDS once by stage_all(); no barriers.
+// SRC_LDSN : tiles of P.tile_cap objects staged by the whole workgroup; EVERY thread of the
+//            workgroup must call this the same number of times (barriers inside).
+struct LdsView {
+    double *m;      // [cap][12]
+    double *prim;   // [cap][4]
+    uint32_t *kind; // [cap]
+};
+
+DEVI LdsView lds_view(double *base, uint32_t cap) {
+    LdsView v;
+    v.m = base;
+    v.prim = base + (size_t)cap * 12;
+    v.kind = reinterpret_cast<uint32_t *>(base + (size_t)cap * 16);
+    return v;
+}
+
+DEVI void stage_tile(const RenderParams &P, const LdsView &L, uint32_t base, uint32_t cnt) {
+    const double *gm = reinterpret_cast<const double *>(P.isect + base);
+    for (uint32_t e = threadIdx.x; e < cnt * 12; e += RTC_BLOCK) L.m[e] = gm[e];
+    const double *gp = reinterpret_cast<const double *>(P.prim + base);
+    for (uint32_t e = threadIdx.x; e < cnt * 4; e += RTC_BLOCK) L.prim[e] = gp[e];
+    for (uint32_t e = threadIdx.x; e < cnt; e += RTC_BLOCK) L.kind[e] = P.kind[base + e];
+}
+
+template <int SRC, class F>
+DEVI void for_each_object(const RenderParams &P, const LdsView &L, bool lane_needs, F &&f) {
+    if constexpr (SRC == SRC_SMEM) {
+        if (ballot(lane_needs) == 0ull) return;
+        for (uint32_t j = 0; j < P.n; ++j) {
+            const DevIsect *rec = P.isect + j;
+            if (!f((int)j, rec->m, P.kind[j], reinterpret_cast<const double *>(P.prim + j))) break;
+        }
+    } else if constexpr (SRC == SRC_LDS1) {
+        if (ballot(lane_needs) == 0ull) return;
+        for (uint32_t j = 0; j < P.n; ++j) {
+            const uint32_t kind = __builtin_amdgcn_readfirstlane(L.kind[j]);
+            if (!f((int)j, L.m + j * 12, kind, L.prim + j * 4)) break;
+        }
+    } else {
+        bool wave_live = ballot(lane_needs) != 0ull;
+        for (uint32_t base = 0; base < P.n; base += P.tile_cap) {
+            const uint32_t cnt = (P.n - base < P.tile_cap) ? (P.n - base) : P.tile_cap;
+            __syncthreads(); // previous tile fully consumed
+            stage_tile(P, L, base, cnt);
+            __syncthreads();
+            if (wave_live) {
+                for (uint32_t j = 0; j < cnt; ++j) {
+                    const uint32_t kind = __builtin_amdgcn_readfirstlane(L.kind[j]);
+                    if (!f((int)(base + j), L.m + j * 12, kind, L.prim + j * 4)) { wave_live = false; break; }
+                }
+            }
+        }
+    }
+}
+
+// ---- patterns (material.rs:41-45 and the six pattern_at bodies) --------------------------
+DEVI V3 pattern_color(const DevShade *S, const double *m_obj, V3 world_point) {
+    const V3 op = xpoint(m_obj, world_point);
+    const V3 pp = xpoint(S->pat_inv, op);
+    const V3 a = mk(S->pat_a[0], S->pat_a[1], S->pat_a[2]);
+    const V3 b = mk(S->pat_b[0], S->pat_b[1], S->pat_b[2]);
+    switch (S->pattern_kind) {
+    case RTC_PATTERN_TEST: return pp;
+    case RTC_PATTERN_STRIPE: return (fmod(floor(pp.x), 2.0) == 0.) ? a : b;
+    case RTC_PATTERN_GRADIENT: {
+        const V3 diff = vsub(b, a); // GradientPattern::new: _diff = b.sub(a)
+        return vadd(a, vmul(diff, pp.x - floor(pp.x)));
+    }
+    case RTC_PATTERN_RING: return (fmod(floor(sqrt(pp.x * pp.x + pp.y * pp.y)), 2.0) == 0.0) ? a : b;
+    case RTC_PATTERN_CHECKER: return (fmod(floor(pp.x) + floor(pp.y) + floor(pp.z), 2.0) == 0.0) ? a : b;
+    case RTC_PATTERN_GRID:
+        return (fabs(pp.x - floor(pp.x)) < 0.01 || fabs(pp.z - floor(pp.z)) < 0.01) ? b : a;
+    default: return mk(0., 0., 0.);
+    }
+}
+
+// Material::lighting material.rs:319-361. lightv = (light.position - point).normalize() is
+// the shadow ray's direction (same expression, shape.rs:717-719), passed in.
+DEVI V3 lighting(const RenderParams &P, const DevShade *S, const double *m_obj, V3 point, V3 eyev, V3 normal,
+                 V3 lightv, bool in_shadow) {
+    const V3 I = mk(P.light_int[0], P.light_int[1], P.light_int[2]);
+    const V3 base = (S->pattern_kind != RTC_PATTERN_NONE) ? pattern_color(S, m_obj, point)
+                                                          : mk(S->color[0], S->color[1], S->color[2]);
+    const V3 eff = vmulv(base, I);
+    const V3 ambient = vmul(eff, S->ambient);
+    if (in_shadow) return ambient;
+    const double ldn = vdot(lightv, normal);
+    V3 diffuse = mk(0., 0., 0.), specular = mk(0., 0., 0.);
+    if (!(ldn < 0.)) {
+        diffuse = vmul(eff, S->diffuse * ldn);
+        const V3 reflectv = vreflect(vneg(lightv), normal);
+        const double rde = vdot(reflectv, eyev);
+        if (!(rde <= 0.)) {
+            const double factor = pow(rde, S->shininess);
+            specular = vmul(I, S->specular * factor);
+        }
+    }
+    return vadd(vadd(ambient, diffuse), specular);
+}
+
+// World::reflectance (Schlick) shape.rs:768-781
+DEVI double reflectance(V3 eyev, V3 normal, double n1, double n2) {
+    double cosv = vdot(eyev, normal);
+    if (n1 > n2) {
+        const double n = n1 / n2;
+        const double sin2_t = (n * n) * (1.0 - cosv * cosv);
+        if (sin2_t > 1.0) return 1.0;
+        cosv = sqrt(1.0 - sin2_t);
+    }
+    const double q = (n1 - n2) / (n1 + n2);
+    const double r0 = q * q;
+    const double x = 1.0 - cosv;
+    const double x2 = x * x;
+    return r0 + (1.0 - r0) * (x * (x2 * x2)); // powi(5)
+}
+
+struct Frame {
+    V3 surface;
+    V3 reflected;
+    V3 ro, rd;      // pending refraction ray
+    double kr, tr, R;
+    uint8_t rem;    // `remaining` of the color_at call that owns the frame
+    uint8_t state;  // 0 waiting for the reflected child, 1 waiting for the refracted child
+    uint8_t schlick;
+    uint8_t has_refr;
+};
+
+// shade_hit's final combination shape.rs:692-699
+DEVI V3 combine(V3 surface, V3 reflected, V3 refracted, bool schlick, double R) {
+    if (schlick) return vadd(surface, vadd(vmul(reflected, R), vmul(refracted, 1.0 - R)));
+    return vadd(vadd(surface, reflected), refracted);
+}
+
+// ---- the kernel -------------------------------------------------------------------------
+template <int SRC, bool REFL, bool REFR>
+__global__ void __launch_bounds__(RTC_BLOCK) k_trace(const RenderParams P) {
+    extern __shared__ double lds_raw[];
+    const LdsView L = lds_view(lds_raw, P.tile_cap);
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const bool probe = P.rays != nullptr;
+
+    // XCD-aware remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs;
+    // give each XCD a contiguous run of logical tiles (bijective for any grid size).
+    uint32_t bid = blockIdx.x;
+    {
+        const uint32_t nb = gridDim.x, q = nb / 8u, r = nb % 8u, xcd = bid % 8u, k = bid / 8u;
+        bid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + k;
+    }
+
+    uint32_t px = 0, py = 0, ray_index = 0;
+    bool in_range, traced;
+    if (probe) {
+        ray_index = bid * RTC_BLOCK + threadIdx.x;
+        in_range = ray_index < P.nrays;
+        traced = in_range;
+    } else {
+        const uint32_t bx = bid % P.grid_x, by = bid / P.grid_x;
+        px = bx * 32u + wave * 8u + (lane & 7u);
+        py = P.y0 + by * 8u + (lane >> 3);
+        in_range = px < P.W && py < P.y1;
+        // Camera::render leaves the last row and column untouched (camera.rs:120-121)
+        traced = in_range && !(P.mode == RTC_MODE_RENDER && (px + 1u >= P.W || py + 1u >= P.H));
+    }
+
+    if constexpr (SRC == SRC_LDS1) {
+        stage_tile(P, L, 0, P.n);
+        __syncthreads();
+    }
+
+    const V3 lightp = mk(P.light_pos[0], P.light_pos[1], P.light_pos[2]);
+    // ray origin of every primary ray: transform_point(view_inv, (0,0,0)) camera.rs:72
+    const V3 cam_origin = xpoint(P.vinv, mk(0., 0., 0.));
+
+    uint32_t c_primary = 0, c_shadow = 0, c_reflect = 0, c_refract = 0; // wave-uniform
+
+    const uint32_t nsamples = (probe || P.samples == 1u) ? 1u : 4u;
+    V3 acc = mk(0., 0., 0.); // Color::average_over running sums color.rs:128-136
+    V3 result = mk(0., 0., 0.);
+
+    Frame stack[REFL ? RTC_MAX_STACK : 1];
+
+    for (uint32_t s = 0; s < nsamples; ++s) {
+        V3 ro, rd;
+        bool shared_origin;
+        if (probe) {
+            const double *rp = P.rays + (size_t)(in_range ? ray_index : 0u) * 6;
+            ro = mk(rp[0], rp[1], rp[2]);
+            rd = mk(rp[3], rp[4], rp[5]);
+            shared_origin = false;
+        } else {
+            // Camera::ray_for_pixel_offset camera.rs:64-76; sub-sample offsets camera.rs:98,102-105
+            const double xo = (nsamples == 1u) ? 0.5 : ((s & 1u) ? 0.75 : 0.25);
+            const double yo = (nsamples == 1u) ? 0.5 : ((s & 2u) ? 0.75 : 0.25);
+            const double xoffset = ((double)px + xo) * P.pixel_size;
+            const double yoffset = ((double)py + yo) * P.pixel_size;
+            const double world_x = P.half_width - xoffset;
+            const double world_y = P.half_height - yoffset;
+            const V3 pixel = xpoint(P.vinv, mk(world_x, world_y, -1.));
+            ro = cam_origin;
+            rd = vnormalize(vsub(pixel, cam_origin));
+            shared_origin = true;
+        }
+
+        bool tracing = traced;
+        bool first = true; // this ray is the one color_at was called with (depth 0)
+        int rem = (int)P.remaining;
+        int sp = 0;
+        c_primary += popc64(ballot(tracing));
+
+        for (;;) {
+            bool any_tracing;
+            if constexpr (SRC == SRC_LDSN) any_tracing = __syncthreads_or(tracing ? 1 : 0) != 0;
+            else any_tracing = ballot(tracing) != 0ull;
+            if (!any_tracing) break;
+
+            // ---- World::intersect + get_hit (shape.rs:677-683, 220-232), streaming form ----
+            double best = __builtin_inf();
+            int hidx = -1, hroot = 0;
+            if (shared_origin && first) {
+                for_each_object<SRC>(P, L, tracing, [&](int j, auto m, uint32_t kind, auto pr) {
+                    if (tracing) {
+                        const V3 o = mk(pr[0], pr[1], pr[2]);
+                        const V3 d = xvector(m, rd);
+                        closest_update<true>(kind, o, d, pr[3], j, best, hidx, hroot);
+                    }
+                    return true;
+                });
+            } else {
+                for_each_object<SRC>(P, L, tracing, [&](int j, auto m, uint32_t kind, auto pr) {
+                    if (tracing) {
+                        const V3 o = xpoint(m, ro);
+                        const V3 d = xvector(m, rd);
+                        closest_update<false>(kind, o, d, 0., j, best, hidx, hroot);
+                    }
+                    return true;
+                });
+            }
+            const bool hit = tracing && hidx >= 0;
+
+            // ---- Intersection::compute_vectors (shape.rs:144-152, 75-96) --------------------
+            V3 point = mk(0, 0, 0), eyev = mk(0, 0, 0), normal = mk(0, 0, 0), over = mk(0, 0, 0), under = mk(0, 0, 0),
+               reflectv = mk(0, 0, 0), sdir = mk(0, 0, 0);
+            double sdist = 0., n1 = 1.0, n2 = 1.0, m_kr = 0., m_tr = 0.;
+            bool inside = false;
+            const DevShade *S = P.shade + (hit ? hidx : 0);
+            const double *m_obj = P.isect[hit ? hidx : 0].m;
+            if (hit) {
+                point = vadd(ro, vmul(rd, best)); // Ray::position vec.rs:207-209
+                eyev = vneg(rd);
+                // Shape::normal_at shape.rs:34-40
+                const V3 lp = xpoint(m_obj, point);
+                V3 ln;
+                const uint32_t kind = S->kind;
+                if (kind == RTC_SPHERE) ln = mk(lp.x - 0., lp.y - 0., lp.z - 0.);
+                else if (kind == RTC_PLANE) ln = mk(0., 1., 0.);
+                else { // Cube::normal_at_local shape.rs:601-610
+                    const double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
+                    const double maxc = fmax(ax, fmax(ay, az));
+                    if (maxc == ax) ln = mk(lp.x, 0., 0.);
+                    else if (maxc == ay) ln = mk(0., lp.y, 0.);
+                    else ln = mk(0., 0., lp.z);
+                }
+                normal = vnormalize(xvector3(S->nt, ln));
+                inside = vdot(normal, eyev) < 0.0;
+                if (inside) normal = vneg(normal);
+                over = vadd(point, vmul(normal, RTC_EPSILON));
+                under = vsub(point, vmul(normal, RTC_EPSILON));
+                reflectv = vreflect(rd, normal);
+                m_kr = S->reflective;
+                m_tr = S->transparency;
+                // shadow ray: is_shadowed_by_light shape.rs:716-720
+                const V3 v = vsub(lightp, over);
+                sdist = sqrt(v.x * v.x + v.y * v.y + v.z * v.z);
+                sdir = mk(v.x / sdist, v.y / sdist, v.z / sdist);
+            }
+
+            // ---- compute_refractive (shape.rs:115-141), open-set form, transparent hits only ----
+            if constexpr (REFR) {
+                const bool need = hit && m_tr != 0.0;
+                bool any_need;
+                if constexpr (SRC == SRC_LDSN) any_need = __syncthreads_or(need ? 1 : 0) != 0;
+                else any_need = ballot(need) != 0ull;
+                if (any_need) {
+                    bool have_all = false, have_oth = false;
+                    double key_all = 0., key_oth = 0.;
+                    int idx_all = -1, idx_oth = -1;
+                    for_each_object<SRC>(P, L, need, [&](int j, auto m, uint32_t kind, auto pr) {
+                        if (need) {
+                            const V3 o = xpoint(m, ro);
+                            const V3 d = xvector(m, rd);
+                            double t0 = 0., t1 = 0.;
+                            const int cnt = shape_entries<false>(kind, o, d, 0., t0, t1);
+                            if (cnt > 0) {
+                                bool open;
+                                if (j == hidx) {
+                                    open = (hroot == 1);
+                                } else {
+                                    const bool p1 = t0 < best || (t0 == best && j < hidx);
+                                    const bool p2 = (cnt == 2) && (t1 < best || (t1 == best && j < hidx));
+                                    open = p1 && !p2;
+                                }
+                                if (open) {
+                                    if (!have_all || t0 > key_all || (t0 == key_all && j > idx_all)) { have_all = true; key_all = t0; idx_all = j; }
+                                    if (j != hidx && (!have_oth || t0 > key_oth || (t0 == key_oth && j > idx_oth))) { have_oth = true; key_oth = t0; idx_oth = j; }
+                                }
+                            }
+                        }
+                        return true;
+                    });
+                    if (need) {
+                        n1 = have_all ? P.shade[idx_all].refractive_index : 1.0;
+                        if (hroot == 1) n2 = have_oth ? P.shade[idx_oth].refractive_index : 1.0;
+                        else n2 = S->refractive_index;
+                    }
+                }
+            }
+
+            // ---- is_shadowed (shape.rs:712-727): any-hit with early exit ----------------------
+            bool sh_pending = hit, shadowed = false;
+            c_shadow += popc64(ballot(hit));
+            for_each_object<SRC>(P, L, sh_pending, [&](int j, auto m, uint32_t kind, auto pr) {
+                if (sh_pending) {
+                    const V3 o = xpoint(m, over);
+                    const V3 d = xvector(m, sdir);
+                    if (occludes(kind, o, d, sdist)) { shadowed = true; sh_pending = false; }
+                }
+                return ballot(sh_pending) != 0ull;
+            });
+
+            if (probe && first && in_range && P.hits) {
+                rtc_hit *H = reinterpret_cast<rtc_hit *>(P.hits) + ray_index;
+                H->hit_index = hit ? hidx : -1;
+                H->inside = inside ? 1u : 0u;
+                H->shadowed = shadowed ? 1u : 0u;
+                H->_pad = 0u;
+                H->t = hit ? best : 0.;
+                H->point[0] = point.x; H->point[1] = point.y; H->point[2] = point.z;
+                H->over_point[0] = over.x; H->over_point[1] = over.y; H->over_point[2] = over.z;
+                H->under_point[0] = under.x; H->under_point[1] = under.y; H->under_point[2] = under.z;
+                H->eyev[0] = eyev.x; H->eyev[1] = eyev.y; H->eyev[2] = eyev.z;
+                H->normal[0] = normal.x; H->normal[1] = normal.y; H->normal[2] = normal.z;
+                H->reflectv[0] = reflectv.x; H->reflectv[1] = reflectv.y; H->reflectv[2] = reflectv.z;
+                H->n1 = n1; H->n2 = n2;
+            }
+
+            // ---- shade_hit (shape.rs:685-700) ------------------------------------------------
+            V3 val = mk(0., 0., 0.); // value returned by the color_at call that just finished
+            bool have_val = false;
+            bool l_refl = false, l_refr = false; // this lane launched a reflection / refraction ray
+            if (tracing && !hit) { // background_color: BLACK shape.rs:652-653
+                have_val = true;
+            } else if (hit) {
+                const V3 surface = lighting(P, S, m_obj, over, eyev, normal, sdir, shadowed);
+                bool want_refl = false, want_refr = false;
+                V3 fr_o = mk(0, 0, 0), fr_d = mk(0, 0, 0);
+                if constexpr (REFL) want_refl = (rem != 0) && (m_kr > 0.); // reflected_color shape.rs:730
+                if constexpr (REFR) {
+                    if (rem != 0 && m_tr != 0.0) { // refracted_color shape.rs:751-766
+                        const double n_ratio = n1 / n2;
+                        const double cos_i = vdot(eyev, normal);
+                        const double sin2_t = (n_ratio * n_ratio) * (1.0 - cos_i * cos_i);
+                        if (!(sin2_t > 1.0)) {
+                            const double cos_t = sqrt(1.0 - sin2_t);
+                            fr_d = vsub(vmul(normal, n_ratio * cos_i - cos_t), vmul(eyev, n_ratio));
+                            fr_o = under;
+                            want_refr = true;
+                        }
+                    }
+                }
+                bool schlick = false;
+                double R = 0.;
+                if constexpr (REFR) {
+                    if (m_kr > 0.0 && m_tr > 0.0) { schlick = true; R = reflectance(eyev, normal, n1, n2); }
+                }
+                if (!want_refl && !want_refr) {
+                    val = combine(surface, mk(0., 0., 0.), mk(0., 0., 0.), schlick, R);
+                    have_val = true;
+                } else {
+                    if constexpr (REFL) {
+                        Frame &F = stack[sp];
+                        F.surface = surface;
+                        F.reflected = mk(0., 0., 0.);
+                        F.ro = fr_o; F.rd = fr_d;
+                        F.kr = m_kr; F.tr = m_tr; F.R = R;
+                        F.rem = (uint8_t)rem;
+                        F.state = want_refl ? 0 : 1;
+                        F.schlick = schlick ? 1 : 0;
+                        F.has_refr = want_refr ? 1 : 0;
+                        ++sp;
+                        if (want_refl) { ro = over; rd = reflectv; l_refl = true; } // Ray::new(over_point, reflectv) shape.rs:734
+                        else { ro = fr_o; rd = fr_d; l_refr = true; }               // Ray::new(under_point, direction) shape.rs:764
+                        rem = rem - 1;
+                    }
+                }
+            }
+            first = false;
+
+            // ---- return `val` to the callers (unwind) ------------------------------------------
+            if (have_val) {
+                bool relaunched = false;
+                if constexpr (REFL) {
+                    while (sp > 0) {
+                        Frame &F = stack[sp - 1];
+                        if (F.state == 0) {
+                            F.reflected = vmul(val, F.kr); // c.mul_f64(reflectiveness) shape.rs:736
+                            if (F.has_refr) { // now refracted_color's recursion shape.rs:764-765
+                                F.state = 1;
+                                ro = F.ro; rd = F.rd;
+                                rem = (int)F.rem - 1;
+                                relaunched = true;
+                                l_refr = true;
+                                break;
+                            }
+                            val = combine(F.surface, F.reflected, mk(0., 0., 0.), F.schlick != 0, F.R);
+                            --sp;
+                        } else {
+                            const V3 refracted = vmul(val, F.tr); // shape.rs:765
+                            val = combine(F.surface, F.reflected, refracted, F.schlick != 0, F.R);
+                            --sp;
+                        }
+                    }
+                }
+                if (!relaunched) {
+                    result = val;
+                    tracing = false;
+                }
+            }
+            if constexpr (REFL) {
+                c_reflect += popc64(ballot(l_refl));
+                c_refract += popc64(ballot(l_refr));
+            }
+        }
+
+        if (nsamples > 1u) acc = vadd(acc, result);
+    }
+
+    if (nsamples > 1u) { // Color::average_over color.rs:137-138
+        const double l = (double)nsamples;
+        result = mk(acc.x / l, acc.y / l, acc.z / l);
+    }
+
+    if (in_range) {
+        double *o = probe ? (P.out + (size_t)ray_index * 3) : (P.out + ((size_t)(py - P.y0) * P.W + px) * 3);
+        if (!traced) result = mk(0., 0., 0.); // Canvas::new BLACK canvas.rs:37-41
+        o[0] = result.x;
+        o[1] = result.y;
+        o[2] = result.z;
+    }
+
+    if (P.counters) {
+        const uint32_t npix = popc64(ballot(traced));
+        if (lane == 0) {
+            if (c_primary) atomicAdd(P.counters + CNT_PRIMARY, (unsigned long long)c_primary);
+            if (c_shadow) atomicAdd(P.counters + CNT_SHADOW, (unsigned long long)c_shadow);
+            if (c_reflect) atomicAdd(P.counters + CNT_REFLECT, (unsigned long long)c_reflect);
+            if (c_refract) atomicAdd(P.counters + CNT_REFRACT, (unsigned long long)c_refract);
+            if (npix) atomicAdd(P.counters + CNT_PIXELS, (unsigned long long)npix);
+        }
+    }
+}
+
+// Per-render prologue: camera origin in each object's space and the sphere quadratic's `c`
+// (shape.rs:363,366) — the part of every primary-ray test that does not depend on the pixel.
+__global__ void __launch_bounds__(RTC_BLOCK) k_prep_primary(const DevIsect *isect, DevPrim *prim, uint32_t n,
+                                                            double v0, double v1, double v2, double v3, double v4,
+                                                            double v5, double v6, double v7, double v8, double v9,
+                                                            double v10, double v11) {
+    const uint32_t j = blockIdx.x * RTC_BLOCK + threadIdx.x;
+    if (j >= n) return;
+    const double vinv[12] = {v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11};
+    const V3 origin = xpoint(vinv, mk(0., 0., 0.));
+    const V3 o = xpoint(isect[j].m, origin);
+    prim[j].ox = o.x;
+    prim[j].oy = o.y;
+    prim[j].oz = o.z;
+    prim[j].c = vdot(o, o) - 1.;
+}
+
+// Device arithmetic probe (rtc_device_arith).
+__global__ void k_arith(uint32_t op, const double *a, const double *b, uint32_t n, double *out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double r;
+    switch (op) {
+    case 0: r = sqrt(a[i]); break;
+    case 1: r = a[i] / b[i]; break;
+    case 2: r = pow(a[i], b[i]); break;
+    case 3: r = floor(a[i]); break;
+    default: r = fmod(a[i], 2.0); break;
+    }
+    out[i] = r;
+}
+
+// ---- launchers (called from rtc_api.cpp) --------------------------------------------------
+template <int SRC, bool REFL, bool REFR>
+static hipError_t launch_one(const RenderParams &P, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+    if (lds_bytes > 48 * 1024) { // more dynamic LDS than the default limit: opt in (up to 160 KiB per CU on gfx950)
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace<SRC, REFL, REFR>),
+                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL((k_trace<SRC, REFL, REFR>), grid, dim3(RTC_BLOCK), lds_bytes, stream, P);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rtc_launch_trace(const RenderParams *P, int src, int refl, int refr, uint32_t nblocks,
+                                       size_t lds_bytes, hipStream_t stream) {
+    const dim3 grid(nblocks);
+#define RTC_CASE(S)                                                                            \
+    if (src == S) {                                                                            \
+        if (refr) return launch_one<S, true, true>(*P, grid, lds_bytes, stream);               \
+        if (refl) return launch_one<S, true, false>(*P, grid, lds_bytes, stream);              \
+        return launch_one<S, false, false>(*P, grid, lds_bytes, stream);                       \
+    }
+    RTC_CASE(SRC_SMEM)
+    RTC_CASE(SRC_LDS1)
+    RTC_CASE(SRC_LDSN)
+#undef RTC_CASE
+    return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t rtc_launch_prep(const DevIsect *isect, DevPrim *prim, uint32_t n, const double vinv[12],
+                                      hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prep_primary, dim3((n + RTC_BLOCK - 1) / RTC_BLOCK), dim3(RTC_BLOCK), 0, stream, isect, prim,
+                       n, vinv[0], vinv[1], vinv[2], vinv[3], vinv[4], vinv[5], vinv[6], vinv[7], vinv[8], vinv[9],
+                       vinv[10], vinv[11]);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t rtc_launch_arith(uint32_t op, const double *a, const double *b, uint32_t n, double *out,
+                                       hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_arith, dim3((n + 255) / 256), dim3(256), 0, stream, op, a, b, n, out);
+    return hipGetLastError();
+}
