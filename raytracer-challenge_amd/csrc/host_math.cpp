@@ -8,6 +8,7 @@
 #include "rtc.h"
 
 #include <cmath>
+#include <math.h>
 #include <cstdlib>
 #include <cstring>
 
@@ -123,19 +124,27 @@ void rtc_matrix_scaling(const double m[16], double x, double y, double z, double
     const double e[16] = {x, 0., 0., 0., 0., y, 0., 0., 0., 0., z, 0., 0., 0., 0., 1.};
     left_apply(e, m, out);
 }
+// r.sin() / r.cos() of one angle: an optimised rustc build (x86_64-unknown-linux-gnu) lowers the
+// pair to ONE glibc sincos() call, whose results differ from separate sin()/cos() calls by 1 ulp
+// for about 0.14 % of angles. We follow the release build explicitly (DESIGN.md "sincos").
+static void sin_cos(double r, double &s, double &c) { ::sincos(r, &s, &c); }
+
 void rtc_matrix_rotation_x(const double m[16], double r, double out[16]) { // :71-78
-    const double e[16] = {1., 0., 0., 0., 0., std::cos(r), -std::sin(r), 0.,
-                          0., std::sin(r), std::cos(r), 0., 0., 0., 0., 1.};
+    double sn, cs;
+    sin_cos(r, sn, cs);
+    const double e[16] = {1., 0., 0., 0., 0., cs, -sn, 0., 0., sn, cs, 0., 0., 0., 0., 1.};
     left_apply(e, m, out);
 }
 void rtc_matrix_rotation_y(const double m[16], double r, double out[16]) { // :80-87
-    const double e[16] = {std::cos(r), 0., std::sin(r), 0., 0., 1., 0., 0.,
-                          -std::sin(r), 0., std::cos(r), 0., 0., 0., 0., 1.};
+    double sn, cs;
+    sin_cos(r, sn, cs);
+    const double e[16] = {cs, 0., sn, 0., 0., 1., 0., 0., -sn, 0., cs, 0., 0., 0., 0., 1.};
     left_apply(e, m, out);
 }
 void rtc_matrix_rotation_z(const double m[16], double r, double out[16]) { // :89-96
-    const double e[16] = {std::cos(r), -std::sin(r), 0., 0., std::sin(r), std::cos(r), 0., 0.,
-                          0., 0., 1., 0., 0., 0., 0., 1.};
+    double sn, cs;
+    sin_cos(r, sn, cs);
+    const double e[16] = {cs, -sn, 0., 0., sn, cs, 0., 0., 0., 0., 1., 0., 0., 0., 0., 1.};
     left_apply(e, m, out);
 }
 void rtc_matrix_shearing(const double m[16], double xy, double xz, double yx, double yz,

@@ -14,7 +14,8 @@
 //     make_view_transform(from, to, up)) (camera.rs:33, transform.rs:204).
 //
 // The parser accepts the YAML subset the vocabulary needs: block maps and sequences by
-// indentation, "- key: value" items, flow sequences "[a, b]", comments, plain scalars.
+// indentation, "- key: value" items, flow sequences "[a, b]" and flow maps "{k: v}", comments,
+// plain scalars.
 #include "rtc.h"
 
 #include <cstdio>
@@ -106,8 +107,28 @@ NodeP parse_flow(const std::string &s, size_t &i, int line) {
         }
         return n;
     }
+    if (i < s.size() && s[i] == '{') { // flow map {key: value, ...}
+        n->kind = Node::Map;
+        ++i;
+        for (;;) {
+            while (i < s.size() && s[i] == ' ') ++i;
+            if (i >= s.size()) fail(line, "unterminated '{'");
+            if (s[i] == '}') { ++i; break; }
+            const size_t c = s.find(':', i);
+            if (c == std::string::npos) fail(line, "expected 'key: value' in flow map");
+            const std::string key = strip(s.substr(i, c - i));
+            if (key.empty() || key.find_first_of(",{}[]") != std::string::npos) fail(line, "bad key in flow map");
+            i = c + 1;
+            n->map.emplace_back(key, parse_flow(s, i, line));
+            while (i < s.size() && s[i] == ' ') ++i;
+            if (i < s.size() && s[i] == ',') { ++i; continue; }
+            if (i < s.size() && s[i] == '}') { ++i; break; }
+            fail(line, "expected ',' or '}' in flow map");
+        }
+        return n;
+    }
     size_t start = i;
-    while (i < s.size() && s[i] != ',' && s[i] != ']') ++i;
+    while (i < s.size() && s[i] != ',' && s[i] != ']' && s[i] != '}') ++i;
     n->kind = Node::Scalar;
     n->scalar = strip(s.substr(start, i - start));
     if (n->scalar.size() >= 2 && ((n->scalar.front() == '"' && n->scalar.back() == '"') ||
@@ -120,7 +141,7 @@ NodeP parse_inline_value(const std::string &s, int line) {
     size_t i = 0;
     NodeP n = parse_flow(s, i, line);
     while (i < s.size() && s[i] == ' ') ++i;
-    if (i != s.size() && n->kind == Node::Seq) fail(line, "trailing characters after ']'");
+    if (i != s.size() && n->kind != Node::Scalar) fail(line, "trailing characters after flow value");
     if (n->kind == Node::Scalar) n->scalar = strip(s);
     return n;
 }
