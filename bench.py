@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path's headline metric on MI355X.
+
+Metric (BASELINE.json): Mrays/sec (primary+shadow), 1920x1080 x 100 spheres; 1/2/4/8 MI355X.
+A step = one frame: Camera::render_async over the synthetic N-sphere scene (SURVEY.md §8d,
+SplitMix64 seed 13) with the World and the Canvas tile resident in HBM. With --gpus N the frame
+is row-tiled (rank r renders rows [r*H/N, (r+1)*H/N)) and the tiles are gathered to rank 0 with
+one RCCL gather — total work is fixed, so scaling is "strong".
+
+Prints ONE JSON line on rank 0. `roofline` is the HBM view the north star asks for (algorithmic
+bytes / kernel time vs 8 TB/s); the path is f64-VALU bound, so `valu_roofline` carries the
+figure that actually binds (algorithmic f64 flops vs 39.3 T f64-instr/s with FMA contraction off).
+`cpu_baseline` times the CPU oracle (a port of the Rust path; the Rust sources cannot be built
+here) on the host cores, rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path[:0] = [str(ROOT), str(ROOT / "oracle")]
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TINSTR = 39.3      # 78.6 TFLOP/s FP64 vector counts FMA as 2; contraction is off here
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--spheres", type=int, default=100)
+    ap.add_argument("--no-plane", action="store_true")
+    ap.add_argument("--reflective", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (bounded sample)")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(W, rows, world):
+    """24 B per pixel written once + the scene read once."""
+    n = len(world)
+    n_pat = sum(1 for s in world.shapes if s.material.pattern_kind != 0)
+    return 24 * W * rows + 400 * n + 128 * n_pat + 200
+
+
+def algorithmic_flops(world, rays_total, hits):
+    """54 f64 flop per (ray, sphere), 33 per (ray, plane), ~200 per hit."""
+    per_ray = sum(54 if s.kind == 0 else 33 if s.kind == 1 else 60 for s in world.shapes)
+    return rays_total * per_ray + hits * 200
+
+
+def main():
+    args = parse()
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world_size:
+        if world_size == 1 and args.gpus > 1:
+            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback for the render path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world_size > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+
+    from _bootstrap import package
+    rtc = package()
+    scenes = importlib.import_module(rtc.__name__ + ".scenes")
+    tiles = importlib.import_module(rtc.__name__ + ".tiles")
+
+    W, H = args.width, args.height
+    world, cam = scenes.synthetic(args.spheres, W, H, with_plane=not args.no_plane, reflective=args.reflective)
+    y0, y1 = tiles.row_range(H, world_size, rank)
+    rows_max = tiles.rows_per_rank(H, world_size)
+
+    # launch on torch's current stream so that torch events and RCCL order against the kernels
+    stream = torch.cuda.current_stream(dev)
+    ctx = rtc.Context(local_rank, stream=stream.cuda_stream)
+    dworld = ctx.upload(world)
+    tile = torch.zeros((rows_max, W, 3), dtype=torch.float64, device=dev)
+    canvas = torch.empty((world_size * rows_max, W, 3), dtype=torch.float64, device=dev) if (rank == 0 and world_size > 1) else None
+
+    def step(ev=None):
+        if ev:
+            ev[0].record(stream)
+        dworld.render_rows(cam, y0, y1, tile.data_ptr(), rtc.MODE_RENDER_ASYNC)
+        if ev:
+            ev[1].record(stream)
+        if world_size > 1:
+            tiles.gather_tiles(tile, canvas, world_size, rank)
+
+    for _ in range(args.warmup):
+        step()
+    ctx.reset_stats()
+    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world_size > 1:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(events[k])
+    torch.cuda.synchronize(dev)
+    if world_size > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+
+    st = ctx.stats()
+    kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
+    last_ms = ctx.last_kernel_ms()
+    agg = torch.tensor([elapsed, float(st["rays_primary"]), float(st["rays_shadow"]), float(st["rays_reflect"] + st["rays_refract"]),
+                        kernel_ms], dtype=torch.float64, device=dev)
+    if world_size > 1:
+        tmax = agg[[0, 4]].clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
+        elapsed, kernel_ms_max = float(tmax[0]), float(tmax[1])
+    else:
+        kernel_ms_max = kernel_ms
+    rays_ps = float(agg[1] + agg[2])          # primary + shadow, whole job, over the timed steps
+    rays_other = float(agg[3])
+
+    if rank == 0:
+        steps = max(1, args.steps)
+        value = rays_ps / elapsed / 1e6
+        rows = y1 - y0
+        abytes = algorithmic_bytes(W, rows, world)
+        rays_rank = (st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"] + st["rays_refract"]) / steps
+        hits_rank = st["rays_shadow"] / steps  # one shadow ray per shaded hit (shape.rs:688)
+        aflops = algorithmic_flops(world, rays_rank, hits_rank)
+        out = {
+            "metric": "Mrays/sec (primary+shadow)",
+            "value": round(value, 3),
+            "unit": "Mrays/s",
+            "n_gpus": world_size,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{W}x{H}, {args.spheres} spheres" + ("" if args.no_plane else " + checker floor plane") +
+                            ", 1 point light, render_async, SplitMix64 seed 13" + (", reflective depth 5" if args.reflective else ""),
+                "objects": len(world), "rows_per_gpu": rows, "parallelism": f"row-tiles x{world_size} + RCCL gather" if world_size > 1 else "single GPU",
+                "rays_per_frame_primary_shadow": int(round(rays_ps / steps)), "rays_per_frame_other": int(round(rays_other / steps)),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "k_trace", "achieved": round(abytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6), "traffic": None,
+                "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": round(kernel_ms, 5), "kernel_ms_last_launch": round(last_ms, 5),
+                "note": "path is f64-VALU bound, not HBM bound: see valu_roofline",
+            },
+            "valu_roofline": {
+                "bound": "fp64_valu_no_fma", "achieved": round(aflops / (kernel_ms * 1e-3) / 1e12, 4), "peak": FP64_PEAK_TINSTR,
+                "unit": "T f64-instr/s", "frac": round(aflops / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TINSTR, 5),
+                "algorithmic_flops_per_launch": int(aflops),
+            },
+            "device": ctx.device_info(),
+        }
+        if world_size > 1:
+            out["config"]["kernel_ms_max_over_ranks"] = round(kernel_ms_max, 5)
+        if world_size == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(world, cam, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+
+    dworld.close()
+    ctx.close()
+    if world_size > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(world, cam, budget_s):
+    """The CPU oracle (a C port of the Rust path, literal sorted-list form) on the host cores,
+    same scene; bounded sample: as many whole frames (or one band of rows) as fit the budget."""
+    import oracle as O
+    O.build()
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = max(1, min(cores, 64))
+    arr = world.array()
+    H = cam.vsize
+    # probe: a thin band to estimate the rate, then size the sample
+    band = max(1, H // 60)
+    t = time.perf_counter()
+    _, st = O.render(arr, len(world), world.light, cam, mode=1, y0=H // 2, y1=H // 2 + band, nthreads=cores, want_stats=True)
+    dt = max(1e-6, time.perf_counter() - t)
+    est_frame = dt * H / band
+    if est_frame <= budget_s:
+        frames = max(1, int(budget_s / est_frame))
+        t = time.perf_counter()
+        rays = 0
+        for _ in range(frames):
+            _, st = O.render(arr, len(world), world.light, cam, mode=1, nthreads=cores, want_stats=True)
+            rays += st["rays_primary"] + st["rays_shadow"]
+        dt = time.perf_counter() - t
+        sample = f"{frames} full frame(s) {cam.hsize}x{cam.vsize}"
+    else:
+        rows = max(band, int(H * budget_s / est_frame))
+        ya = (H - rows) // 2
+        t = time.perf_counter()
+        _, st = O.render(arr, len(world), world.light, cam, mode=1, y0=ya, y1=ya + rows, nthreads=cores, want_stats=True)
+        dt = time.perf_counter() - t
+        rays = st["rays_primary"] + st["rays_shadow"]
+        sample = f"rows [{ya},{ya + rows}) of {cam.hsize}x{cam.vsize} (centre band)"
+    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample,
+            "seconds": round(dt, 2), "form": "literal sorted-list oracle (oracle/rtc_oracle.c), f64, -O2 -ffp-contract=off"}
+
+
+if __name__ == "__main__":
+    main()

@@ -10,6 +10,7 @@
 
 #include <math.h>
 #include <pthread.h>
+#include <stdatomic.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -752,7 +753,8 @@ static void render_pixel(trace_t *T, const rtc_camera *cam, uint32_t x, uint32_t
 
 typedef struct {
     const rtc_shape *shapes; uint32_t n; const rtc_light *light; const rtc_camera *cam;
-    uint32_t mode, y0, ya, yb; double *rgb; int streaming; counters_t cnt; uint64_t pixels;
+    uint32_t mode, y0, y1; double *rgb; int streaming; counters_t cnt; uint64_t pixels;
+    atomic_uint *next_row; /* shared work queue: workers take one canvas row at a time */
 } job_t;
 
 static void *render_rows(void *arg) {
@@ -762,7 +764,9 @@ static void *render_rows(void *arg) {
     j->pixels = 0;
     if (trace_init(&T, j->shapes, j->n, j->light, &j->cnt, j->streaming)) return NULL;
     uint32_t W = j->cam->hsize, H = j->cam->vsize;
-    for (uint32_t y = j->ya; y < j->yb; y++)
+    for (;;) {
+        uint32_t y = atomic_fetch_add(j->next_row, 1u);
+        if (y >= j->y1) break;
         for (uint32_t x = 0; x < W; x++) {
             double *px = j->rgb + ((size_t)(y - j->y0) * W + x) * 3;
             /* Camera::render loops 0..vsize-1 and 0..hsize-1 EXCLUSIVE (camera.rs:120-121);
@@ -771,6 +775,7 @@ static void *render_rows(void *arg) {
             render_pixel(&T, j->cam, x, y, px);
             j->pixels++;
         }
+    }
     trace_free(&T);
     return NULL;
 }
@@ -783,12 +788,12 @@ void orc_render(const rtc_shape *shapes, uint32_t n, const rtc_light *light, con
     if (nthreads > rows && rows > 0) nthreads = rows;
     job_t *jobs = (job_t *)calloc(nthreads, sizeof(job_t));
     pthread_t *th = (pthread_t *)calloc(nthreads, sizeof(pthread_t));
+    atomic_uint next_row;
+    atomic_init(&next_row, y0);
     for (uint32_t t = 0; t < nthreads; t++) {
         job_t *j = &jobs[t];
-        j->shapes = shapes; j->n = n; j->light = light; j->cam = cam; j->mode = mode; j->y0 = y0;
-        j->ya = y0 + (uint32_t)(((uint64_t)rows * t) / nthreads);
-        j->yb = y0 + (uint32_t)(((uint64_t)rows * (t + 1)) / nthreads);
-        j->rgb = rgb; j->streaming = streaming;
+        j->shapes = shapes; j->n = n; j->light = light; j->cam = cam; j->mode = mode; j->y0 = y0; j->y1 = y1;
+        j->rgb = rgb; j->streaming = streaming; j->next_row = &next_row;
         if (nthreads == 1) render_rows(j);
         else pthread_create(&th[t], NULL, render_rows, j);
     }

@@ -10,8 +10,8 @@
  * Pinning: the reference is Rust and no Rust toolchain exists in the build container
  * (SURVEY.md F2), so the reference itself cannot be run; this restatement is pinned by
  * every known-answer test the reference's own #[cfg(test)] modules hold for the path
- * (SURVEY.md App. D), transcribed as data in tests/golden/reference_kats.json and
- * checked by tests/test_oracle_kats.py.
+ * (SURVEY.md App. D), transcribed test by test (inputs and expected values, with the
+ * reference file:line of each) in tests/test_oracle_kats.py.
  *
  * It shares only the plain-data scene structs of include/rtc.h with the product.
  * Compile: gcc -O2 -ffp-contract=off -fno-fast-math (see oracle/Makefile).
@@ -105,7 +105,7 @@ void   orc_pattern_at_shape(const rtc_material *m, const rtc_shape *shape,
 
 /* ---- camera.rs render drivers + canvas.rs ------------------------------------------ */
 /* Camera::render (mode RTC_MODE_RENDER, :116-126) / render_async (:144-160) for rows
- * [y0,y1) into rgb ((y1-y0)*hsize*3). nthreads >= 1 (contiguous row blocks).
+ * [y0,y1) into rgb ((y1-y0)*hsize*3). nthreads >= 1 (rows are handed out dynamically, like rayon).
  * streaming != 0 uses the streaming formulation. stats may be NULL. */
 void   orc_render(const rtc_shape *shapes, uint32_t n, const rtc_light *light,
                   const rtc_camera *cam, uint32_t mode, uint32_t y0, uint32_t y1,

@@ -12,6 +12,7 @@ calls raise.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 from pathlib import Path
 
 import numpy as np
@@ -39,6 +40,13 @@ def lib() -> C.CDLL:
         if not LIB_PATH.exists():
             raise RuntimeError(f"{LIB_PATH} is missing: run `python __graft_entry__.py build` (hipcc, gfx950). "
                                "There is no CPU fallback for the render path.")
+        # One HIP runtime per process: PyTorch wheels bundle their own libamdhip64.so.7 (same soname
+        # as /opt/rocm's). Import torch first so that librtc.so binds to the runtime torch uses —
+        # otherwise two HSA runtimes race for the device and the second one sees "no GPUs".
+        try:
+            import torch  # noqa: F401
+        except Exception:  # torch is plumbing (device tensors, streams, RCCL), not a hard dependency
+            pass
         _lib = C.CDLL(str(LIB_PATH))
         declare(_lib)
     return _lib
@@ -249,9 +257,15 @@ class Context:
         _check(lib().rtc_context_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)), "rtc_context_create",
                "no usable MI355X (gfx950); this library has no CPU fallback")
         self.device = device
+        self._worlds = []  # weak references to the worlds uploaded through this context
 
     def close(self):
         if self._h:
+            for ref in self._worlds:
+                w = ref()
+                if w is not None:
+                    w.close()
+            self._worlds = []
             lib().rtc_context_destroy(self._h)
             self._h = C.c_void_p()
 
@@ -305,6 +319,7 @@ class DeviceWorld:
         arr = world.array()
         _check(lib().rtc_world_create(ctx._h, arr, len(world.shapes), C.byref(world.light), C.byref(self._h)), "rtc_world_create")
         self.n = len(world.shapes)
+        ctx._worlds.append(weakref.ref(self))
 
     def close(self):
         if self._h:

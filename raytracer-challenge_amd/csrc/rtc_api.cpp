@@ -35,7 +35,8 @@ struct rtc_context {
 };
 
 struct rtc_world {
-    rtc_context *ctx = nullptr;
+    rtc_context *ctx = nullptr; // identity check only; never dereferenced at destroy time
+    int device = -1;
     uint32_t n = 0;
     DevIsect *d_isect = nullptr;
     uint32_t *d_kind = nullptr;
@@ -224,6 +225,7 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
     rtc_world *w = new (std::nothrow) rtc_world;
     if (!w) return RTC_ERR_NOMEM;
     w->ctx = ctx;
+    w->device = ctx->device;
     w->n = n;
     w->light = *light;
     w->any_refl = any_refl;
@@ -248,9 +250,9 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
 
 void rtc_world_destroy(rtc_world *w) {
     if (!w) return;
-    if (w->ctx) {
-        (void)hipSetDevice(w->ctx->device);
-        (void)hipStreamSynchronize(w->ctx->stream);
+    if (w->device >= 0) { // the context may already be gone: synchronise the device, not its stream
+        (void)hipSetDevice(w->device);
+        (void)hipDeviceSynchronize();
     }
     if (w->d_isect) (void)hipFree(w->d_isect);
     if (w->d_kind) (void)hipFree(w->d_kind);

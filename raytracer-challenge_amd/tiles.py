@@ -1,0 +1,35 @@
+"""Row tiling of the Canvas across ranks (one process per GPU) and the gather of tiles to rank 0.
+
+The path shards over pixels with no data dependency (camera.rs:151-156: every pixel depends only
+on the read-only World), so each rank renders a contiguous band of rows and the only exchange is
+one gather of the bands into the reference's row-major Canvas layout (canvas.rs:44) on rank 0 —
+`torch.distributed.gather`, which is RCCL send/recv over xGMI with backend "nccl" on ROCm.
+"""
+from __future__ import annotations
+
+
+def rows_per_rank(height: int, world_size: int) -> int:
+    return -(-height // world_size)
+
+
+def row_range(height: int, world_size: int, rank: int) -> tuple[int, int]:
+    """Rows [y0, y1) owned by `rank`: contiguous bands of ceil(H / world_size) rows."""
+    per = rows_per_rank(height, world_size)
+    y0 = min(height, rank * per)
+    return y0, min(height, y0 + per)
+
+
+def gather_tiles(tile, canvas, world_size: int, rank: int, group=None) -> None:
+    """Gather every rank's (rows_per_rank, W, 3) tile into `canvas` ((world_size*rows_per_rank, W, 3))
+    on rank 0. Bands are contiguous, so the gather lands each tile at its final place."""
+    import torch.distributed as dist
+
+    if rank == 0:
+        dist.gather(tile, list(canvas.chunk(world_size, dim=0)), dst=0, group=group)
+    else:
+        dist.gather(tile, None, dst=0, group=group)
+
+
+def assemble(canvas, height: int):
+    """The full Canvas: the first `height` rows of the gathered buffer (the last band may be short)."""
+    return canvas[:height]
