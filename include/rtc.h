@@ -229,7 +229,8 @@ size_t      rtc_canvas_format_ppm(const double *rgb, uint32_t width, uint32_t he
 /* ==== [device] the hot path on one MI355X ========================================== */
 
 /* Create a context on HIP device `device`. `stream` is an existing hipStream_t passed as
- * void* (e.g. torch's current stream) or NULL for a stream owned by the context. */
+ * void* (e.g. torch's current stream); NULL is the device's default stream. The context never
+ * owns the stream. */
 rtc_status  rtc_context_create(int32_t device, void *stream, rtc_context **out);
 void        rtc_context_destroy(rtc_context *ctx);
 rtc_status  rtc_context_synchronize(rtc_context *ctx);

@@ -254,7 +254,7 @@ class Context:
 
     def __init__(self, device: int = 0, stream: int | None = None):
         self._h = C.c_void_p()
-        _check(lib().rtc_context_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)), "rtc_context_create",
+        _check(lib().rtc_context_create(device, C.c_void_p(stream or None), C.byref(self._h)), "rtc_context_create",
                "no usable MI355X (gfx950); this library has no CPU fallback")
         self.device = device
         self._worlds = []  # weak references to the worlds uploaded through this context

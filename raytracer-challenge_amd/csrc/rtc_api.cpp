@@ -26,7 +26,6 @@ enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2 };
 struct rtc_context {
     int device = -1;
     hipStream_t stream = nullptr;
-    bool owns_stream = false;
     unsigned long long *d_counters = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool have_timing = false;
@@ -119,12 +118,8 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
     rtc_context *ctx = new (std::nothrow) rtc_context;
     if (!ctx) return RTC_ERR_NOMEM;
     ctx->device = device;
-    if (stream) {
-        ctx->stream = static_cast<hipStream_t>(stream);
-    } else {
-        if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return RTC_ERR_DEVICE; }
-        ctx->owns_stream = true;
-    }
+    ctx->stream = static_cast<hipStream_t>(stream); // NULL = the device's default stream
+
     if (hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * CNT_N) != hipSuccess ||
         hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
@@ -146,11 +141,10 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
 void rtc_context_destroy(rtc_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
-    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
