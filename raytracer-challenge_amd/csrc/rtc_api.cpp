@@ -21,7 +21,7 @@ extern "C" hipError_t rtc_launch_prep(const DevIsect *isect, DevPrim *prim, uint
 extern "C" hipError_t rtc_launch_arith(uint32_t op, const double *a, const double *b, uint32_t n, double *out,
                                        hipStream_t stream);
 
-enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2 };
+enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2, SRC_CULL = 3 };
 
 struct rtc_context {
     int device = -1;
@@ -58,11 +58,12 @@ struct DeviceGuard { // make ctx->device current for the calling thread
     bool ok;
 };
 
-void choose_source(const rtc_context *ctx, uint32_t n, int *src, uint32_t *tile_cap, size_t *lds_bytes) {
+void choose_source(const rtc_context *ctx, uint32_t n, uint32_t flags, int *src, uint32_t *tile_cap, size_t *lds_bytes) {
     // per object in LDS: 96 B inverse rows + 32 B primary prologue + 4 B kind
     const uint32_t per_obj = 96 + 32 + 4;
     int s;
     if (ctx->force_src >= 0) s = ctx->force_src;
+    else if (!(flags & RTC_FLAG_NO_CULL)) s = SRC_CULL; // default: per-wave conservative cull
     else if (n <= 128) s = SRC_SMEM;
     else if (n <= 448) s = SRC_LDS1;
     else s = SRC_LDSN;
@@ -72,11 +73,102 @@ void choose_source(const rtc_context *ctx, uint32_t n, int *src, uint32_t *tile_
         else cap = n ? n : 1;
     }
     if (s == SRC_LDSN) cap = ctx->tile_cap;
-    if (s == SRC_SMEM) cap = 0;
+    if (s == SRC_SMEM || s == SRC_CULL) cap = 0;
     *src = s;
     *tile_cap = cap;
     // kinds sit behind cap*16 doubles; round the block up to 16 bytes
     *lds_bytes = cap ? (((size_t)cap * per_obj + 15) & ~(size_t)15) : 0;
+}
+
+// World-space bounding sphere of a shape, derived from the stored inverse transform only (that is
+// what the kernels intersect with): the surface is { F p : p on the unit sphere / cube } with
+// F = inv^-1 (affine part). Conservative: radius = largest singular value of F's 3x3 (spheres) or
+// the farthest transformed corner (cubes), inflated by 1e-6; anything not clearly well-conditioned
+// gets r = +inf and is simply never culled.
+DevBound bound_of(const rtc_shape &s) {
+    DevBound b{0., 0., 0., INFINITY};
+    if (s.kind == RTC_PLANE) return b;
+    const double *m = s.inv;
+    const double a[3][3] = {{m[0], m[1], m[2]}, {m[4], m[5], m[6]}, {m[8], m[9], m[10]}};
+    const double t[3] = {m[3], m[7], m[11]};
+    for (int i = 0; i < 3; ++i) {
+        if (!std::isfinite(t[i])) return b;
+        for (int j = 0; j < 3; ++j)
+            if (!std::isfinite(a[i][j])) return b;
+    }
+    const double det = a[0][0] * (a[1][1] * a[2][2] - a[1][2] * a[2][1]) - a[0][1] * (a[1][0] * a[2][2] - a[1][2] * a[2][0]) +
+                       a[0][2] * (a[1][0] * a[2][1] - a[1][1] * a[2][0]);
+    if (!(std::fabs(det) > 1e-300) || !std::isfinite(det)) return b;
+    double f[3][3]; // F3 = a^-1 by cofactors
+    f[0][0] = (a[1][1] * a[2][2] - a[1][2] * a[2][1]) / det;
+    f[0][1] = (a[0][2] * a[2][1] - a[0][1] * a[2][2]) / det;
+    f[0][2] = (a[0][1] * a[1][2] - a[0][2] * a[1][1]) / det;
+    f[1][0] = (a[1][2] * a[2][0] - a[1][0] * a[2][2]) / det;
+    f[1][1] = (a[0][0] * a[2][2] - a[0][2] * a[2][0]) / det;
+    f[1][2] = (a[0][2] * a[1][0] - a[0][0] * a[1][2]) / det;
+    f[2][0] = (a[1][0] * a[2][1] - a[1][1] * a[2][0]) / det;
+    f[2][1] = (a[0][1] * a[2][0] - a[0][0] * a[2][1]) / det;
+    f[2][2] = (a[0][0] * a[1][1] - a[0][1] * a[1][0]) / det;
+    double resid = 0., fmaxabs = 0.; // || a F - I ||_max: refuse to trust an ill-conditioned inverse
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) {
+            double v = (i == j) ? -1. : 0.;
+            for (int k = 0; k < 3; ++k) v += a[i][k] * f[k][j];
+            resid = std::fmax(resid, std::fabs(v));
+            fmaxabs = std::fmax(fmaxabs, std::fabs(f[i][j]));
+            if (!std::isfinite(f[i][j])) return b;
+        }
+    if (!(resid < 1e-9)) return b;
+    double c[3];
+    for (int i = 0; i < 3; ++i) c[i] = -(f[i][0] * t[0] + f[i][1] * t[1] + f[i][2] * t[2]);
+    double r2;
+    if (s.kind == RTC_SPHERE) {
+        // lambda_max of S = F F^T by cyclic Jacobi
+        double S[3][3];
+        for (int i = 0; i < 3; ++i)
+            for (int j = 0; j < 3; ++j) S[i][j] = f[i][0] * f[j][0] + f[i][1] * f[j][1] + f[i][2] * f[j][2];
+        for (int sweep = 0; sweep < 30; ++sweep) {
+            const double off = std::fabs(S[0][1]) + std::fabs(S[0][2]) + std::fabs(S[1][2]);
+            if (off < 1e-300) break;
+            for (int p = 0; p < 2; ++p)
+                for (int q = p + 1; q < 3; ++q) {
+                    if (S[p][q] == 0.) continue;
+                    const double th = (S[q][q] - S[p][p]) / (2. * S[p][q]);
+                    const double tt = (th >= 0. ? 1. : -1.) / (std::fabs(th) + std::sqrt(th * th + 1.));
+                    const double cs = 1. / std::sqrt(tt * tt + 1.), sn = tt * cs;
+                    for (int k = 0; k < 3; ++k) { // S <- S J
+                        const double skp = S[k][p], skq = S[k][q];
+                        S[k][p] = cs * skp - sn * skq;
+                        S[k][q] = sn * skp + cs * skq;
+                    }
+                    for (int k = 0; k < 3; ++k) { // S <- J^T S
+                        const double spk = S[p][k], sqk = S[q][k];
+                        S[p][k] = cs * spk - sn * sqk;
+                        S[q][k] = sn * spk + cs * sqk;
+                    }
+                }
+        }
+        // Gershgorin guard on whatever off-diagonal mass is left
+        const double g = std::fabs(S[0][1]) + std::fabs(S[0][2]) + std::fabs(S[1][2]);
+        r2 = std::fmax(S[0][0], std::fmax(S[1][1], S[2][2])) + 2. * g;
+    } else { // cube: farthest of the 8 transformed corners
+        r2 = 0.;
+        for (int k = 0; k < 8; ++k) {
+            const double px = (k & 1) ? 1. : -1., py = (k & 2) ? 1. : -1., pz = (k & 4) ? 1. : -1.;
+            double q = 0.;
+            for (int i = 0; i < 3; ++i) {
+                const double v = f[i][0] * px + f[i][1] * py + f[i][2] * pz;
+                q += v * v;
+            }
+            r2 = std::fmax(r2, q);
+        }
+    }
+    if (!std::isfinite(r2) || !(r2 >= 0.)) return b;
+    const double cn = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    const double r = std::sqrt(r2) * (1. + 1e-6) + 1e-9 * (1. + cn) + 1e-7 * fmaxabs;
+    if (!std::isfinite(r) || !std::isfinite(cn)) return b;
+    b.cx = c[0]; b.cy = c[1]; b.cz = c[2]; b.r = r;
+    return b;
 }
 
 void fill_camera(RenderParams &P, const rtc_camera *cam) {
@@ -120,15 +212,15 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
     ctx->device = device;
     ctx->stream = static_cast<hipStream_t>(stream); // NULL = the device's default stream
 
-    if (hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * CNT_N) != hipSuccess ||
-        hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream) != hipSuccess ||
+    if (hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * CNT_N * CNT_SLOTS) != hipSuccess ||
+        hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N * CNT_SLOTS, ctx->stream) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
         rtc_context_destroy(ctx);
         return RTC_ERR_DEVICE;
     }
     if (const char *e = std::getenv("RTC_SRC")) {
         const int v = std::atoi(e);
-        if (v >= 0 && v <= 2) ctx->force_src = v;
+        if (v >= 0 && v <= 3) ctx->force_src = v;
     }
     if (const char *e = std::getenv("RTC_TILE_CAP")) {
         const int v = std::atoi(e);
@@ -214,7 +306,7 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
         d.world_id = s.world_id;
         if (m.reflective > 0.) any_refl = true;     // reflected_color shape.rs:730
         if (m.transparency != 0.0) any_refr = true; // refracted_color shape.rs:752
-        bound[i] = DevBound{0.f, 0.f, 0.f, INFINITY};
+        bound[i] = bound_of(s);
     }
     rtc_world *w = new (std::nothrow) rtc_world;
     if (!w) return RTC_ERR_NOMEM;
@@ -260,7 +352,6 @@ rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camer
                            uint32_t y1, void *d_rgb, uint32_t flags) {
     if (!ctx || !w || !cam || !d_rgb || w->ctx != ctx) return RTC_ERR_ARG;
     if (mode > RTC_MODE_RENDER_ASYNC || cam->hsize == 0 || cam->vsize == 0 || y0 > y1 || y1 > cam->vsize) return RTC_ERR_ARG;
-    (void)flags;
     HIP_TRY(hipSetDevice(ctx->device));
     if (y0 == y1) return RTC_OK;
     RenderParams P;
@@ -278,8 +369,9 @@ rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camer
     P.grid_y = (y1 - y0 + 7u) / 8u;
     int src;
     size_t lds_bytes;
-    choose_source(ctx, w->n, &src, &P.tile_cap, &lds_bytes);
-    HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.vinv, ctx->stream));
+    choose_source(ctx, w->n, flags, &src, &P.tile_cap, &lds_bytes);
+    P.flags = flags;
+    if (src != SRC_CULL) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.vinv, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y, lds_bytes, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
@@ -290,9 +382,12 @@ rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camer
 rtc_status rtc_stats_read(rtc_context *ctx, rtc_stats *out) {
     if (!ctx || !out) return RTC_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    unsigned long long h[CNT_N];
-    HIP_TRY(hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned long long> slots((size_t)CNT_N * CNT_SLOTS);
+    HIP_TRY(hipMemcpyAsync(slots.data(), ctx->d_counters, sizeof(unsigned long long) * slots.size(), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    unsigned long long h[CNT_N] = {0};
+    for (int sl = 0; sl < CNT_SLOTS; ++sl)
+        for (int k = 0; k < CNT_N; ++k) h[k] += slots[(size_t)sl * CNT_N + k];
     std::memset(out, 0, sizeof *out);
     out->rays_primary = h[CNT_PRIMARY];
     out->rays_shadow = h[CNT_SHADOW];
@@ -305,7 +400,7 @@ rtc_status rtc_stats_read(rtc_context *ctx, rtc_stats *out) {
 rtc_status rtc_stats_reset(rtc_context *ctx) {
     if (!ctx) return RTC_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N, ctx->stream));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N * CNT_SLOTS, ctx->stream));
     return RTC_OK;
 }
 
@@ -339,7 +434,6 @@ rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays
                         uint32_t flags, double *rgb, rtc_hit *hits) {
     if (!ctx || !w || !rays || !rgb || w->ctx != ctx) return RTC_ERR_ARG;
     if (remaining > 7) return RTC_ERR_ARG; // frame stack depth of the kernel (reference uses <= 5)
-    (void)flags;
     if (n == 0) return RTC_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     double *d_rays = nullptr, *d_rgb = nullptr;
@@ -365,7 +459,8 @@ rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays
         P.grid_y = 1;
         int src;
         size_t lds_bytes;
-        choose_source(ctx, w->n, &src, &P.tile_cap, &lds_bytes);
+        choose_source(ctx, w->n, flags, &src, &P.tile_cap, &lds_bytes);
+        P.flags = flags;
         if (rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x, lds_bytes, ctx->stream) != hipSuccess)
             st = RTC_ERR_DEVICE;
     }

@@ -6,7 +6,7 @@
 //                   Shape::intersect needs (vec.rs:211-214, transform.rs:107-128);
 //                   read wave-uniformly through the scalar cache (or staged in LDS tiles).
 //   kind[n]    4 B  RTC_SPHERE / RTC_PLANE / RTC_CUBE.
-//   bound[n]  16 B  f32 world-space bounding sphere (centre, radius) for the conservative cull.
+//   bound[n]  32 B  f64 world-space bounding sphere (centre, radius) for the conservative cull.
 //   shade[n] 320 B  what shade_hit needs for the ONE object a ray hit: inverse-transpose 3x3,
 //                   material scalars, pattern; gathered per lane after the hit is known.
 //   prim[n]   32 B  per-render scratch: the camera origin in object space and `c` of the sphere
@@ -36,10 +36,15 @@ struct DevPrim {
 };
 
 struct DevBound {
-    float cx, cy, cz, r; // r = +inf: unbounded (planes) or not computable -> never culled
+    double cx, cy, cz, r; // world-space bounding sphere; r = +inf: unbounded (planes) or not
+                          // computable -> never culled
 };
 
 enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PIXELS = 4, CNT_N = 8 };
+// Ray counters are kept in CNT_SLOTS replicas (one 64-byte line each); a wave adds to the replica
+// picked by its workgroup id, so no single word sees more than 1/CNT_SLOTS of the atomics. The host
+// sums the replicas (rtc_stats_read).
+enum { CNT_SLOTS = 256 };
 
 struct RenderParams {
     const DevIsect *isect;
@@ -61,6 +66,7 @@ struct RenderParams {
     uint32_t nrays, remaining;
     void *hits; // rtc_hit[nrays] or nullptr
     uint32_t grid_x, grid_y; // logical block grid of the render (for the XCD-aware remap)
+    uint32_t flags;          // RTC_FLAG_*
 };
 
 #endif

@@ -28,7 +28,7 @@
 #define RTC_BLOCK 256
 #define RTC_MAX_STACK 8
 
-enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2 };
+enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2, SRC_CULL = 3 };
 
 struct V3 {
     double x, y, z;
@@ -176,6 +176,141 @@ DEVI bool occludes(uint32_t kind, V3 o, V3 d, double dist) {
     return false;
 }
 
+// ---- wave64 reductions (DPP): inclusive scan inside each row of 16 lanes, then two row
+// broadcasts; the total lands in lane 63. All 64 lanes must execute these (converged code);
+// lanes that do not take part pass the identity.
+template <int CTRL, int ROW_MASK> DEVI float dpp_f32(float old, float src) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                 CTRL, ROW_MASK, 0xf, false));
+}
+DEVI float lane63(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+DEVI float wave_sum(float v) {
+    v += dpp_f32<0x111, 0xf>(0.f, v); // row_shr:1
+    v += dpp_f32<0x112, 0xf>(0.f, v); // row_shr:2
+    v += dpp_f32<0x114, 0xf>(0.f, v); // row_shr:4
+    v += dpp_f32<0x118, 0xf>(0.f, v); // row_shr:8
+    v += dpp_f32<0x142, 0xa>(0.f, v); // row_bcast:15 into rows 1,3
+    v += dpp_f32<0x143, 0xc>(0.f, v); // row_bcast:31 into rows 2,3
+    return lane63(v);
+}
+DEVI float wave_max(float v) { // v >= 0 or any finite; identity -inf
+    const float id = -__builtin_inff();
+    v = fmaxf(v, dpp_f32<0x111, 0xf>(id, v));
+    v = fmaxf(v, dpp_f32<0x112, 0xf>(id, v));
+    v = fmaxf(v, dpp_f32<0x114, 0xf>(id, v));
+    v = fmaxf(v, dpp_f32<0x118, 0xf>(id, v));
+    v = fmaxf(v, dpp_f32<0x142, 0xa>(id, v));
+    v = fmaxf(v, dpp_f32<0x143, 0xc>(id, v));
+    return lane63(v);
+}
+DEVI float wave_min(float v) { return -wave_max(-v); }
+
+// ---- conservative per-wave cull ------------------------------------------------------------
+// The rays a wave is about to trace form a bundle: a cone (apex, unit axis, half-angle theta)
+// that contains every active lane's ray, optionally fattened by the spread `rho` of the ray
+// origins around the apex and cut at distance `tmax`. An object whose world-space bounding
+// sphere (centre C, radius R, DevBound) cannot touch the bundle cannot produce an intersection
+// with t >= 0 for any lane, so skipping it leaves the closest hit / shadow bit unchanged — the
+// objects that survive are visited in insertion order and tested with the exact f64 arithmetic.
+// The bundle is built in f32 (cheap DPP reductions) and widened by far more than the f32 error;
+// the per-object test is f64 and square-root free.
+struct Bundle {
+    double px, py, pz;   // apex
+    double ax, ay, az;   // axis (unit to ~1e-6)
+    double cosT, sinT;   // half-angle, already widened
+    double rho;          // origin spread around the apex
+    double tmax;         // reach along the rays (inf: unbounded)
+    bool off;            // bundle could not be bounded: every object is a candidate
+};
+
+DEVI bool finite3(V3 v) { return fabs(v.x) < __builtin_inf() && fabs(v.y) < __builtin_inf() && fabs(v.z) < __builtin_inf(); }
+
+// apex_shared: every active lane's ray starts at `apex` (camera origin, or the light for shadow
+// segments walked backwards); otherwise the apex is the centroid of the lanes' origins.
+DEVI Bundle make_bundle(bool active, bool apex_shared, V3 apex, V3 o, V3 d, double reach) {
+    Bundle B;
+    bool bad = active && !(finite3(o) && finite3(d) && (d.x != 0. || d.y != 0. || d.z != 0.));
+    float fx = 0.f, fy = 0.f, fz = 0.f;
+    if (active && !bad) {
+        const float x = (float)d.x, y = (float)d.y, z = (float)d.z;
+        const float l2 = x * x + y * y + z * z;
+        if (l2 > 1e-30f && l2 < 1e30f) {
+            const float il = __builtin_amdgcn_rsqf(l2);
+            fx = x * il; fy = y * il; fz = z * il;
+        } else bad = true;
+    }
+    const float sx = wave_sum(fx), sy = wave_sum(fy), sz = wave_sum(fz);
+    const float s2 = sx * sx + sy * sy + sz * sz;
+    const float is = __builtin_amdgcn_rsqf(fmaxf(s2, 1e-20f));
+    const float ax = sx * is, ay = sy * is, az = sz * is;
+    float c = 1.f, q2 = 0.f;
+    if (active && !bad) {
+        c = ax * fx + ay * fy + az * fz;
+        const float cx = ay * fz - az * fy, cy = az * fx - ax * fz, cz = ax * fy - ay * fx;
+        q2 = cx * cx + cy * cy + cz * cz;
+    }
+    const float cmin = wave_min(c), q2max = wave_max(q2);
+    float rho = 0.f;
+    if (!apex_shared) {
+        const float cnt = wave_sum(active ? 1.f : 0.f);
+        const float mx = wave_sum(active ? (float)o.x : 0.f) / fmaxf(cnt, 1.f);
+        const float my = wave_sum(active ? (float)o.y : 0.f) / fmaxf(cnt, 1.f);
+        const float mz = wave_sum(active ? (float)o.z : 0.f) / fmaxf(cnt, 1.f);
+        apex = mk((double)mx, (double)my, (double)mz);
+        float e2 = 0.f;
+        if (active && !bad) {
+            const double ex = o.x - apex.x, ey = o.y - apex.y, ez = o.z - apex.z;
+            e2 = (float)(ex * ex + ey * ey + ez * ez) * 1.0001f;
+            if (!(e2 < 1e30f)) bad = true;
+        }
+        rho = __builtin_sqrtf(wave_max(e2)) * 1.0001f + 1e-30f;
+        if (!(fabsf(mx) < 1e30f && fabsf(my) < 1e30f && fabsf(mz) < 1e30f)) bad = true;
+    }
+    float tm = 0.f;
+    if (active) tm = (reach < 1e30) ? (float)reach * 1.0001f + 1e-30f : __builtin_inff();
+    const float tmax = wave_max(tm);
+    B.off = (ballot(bad) != 0ull) || !(s2 > 1e-6f) || !(cmin > 0.2f);
+    float sinT, cosT;
+    if (cmin > 0.7f) { // narrow bundle: the cross product resolves small angles, the dot does not
+        sinT = __builtin_sqrtf(q2max) * 1.001f + 4e-6f;
+        cosT = __builtin_sqrtf(fmaxf(0.f, 1.f - sinT * sinT));
+    } else {
+        cosT = cmin - 1e-3f;
+        sinT = __builtin_sqrtf(fmaxf(0.f, 1.f - cosT * cosT)) + 1e-3f;
+    }
+    if (!(sinT < 0.98f)) B.off = true;
+    B.px = apex.x; B.py = apex.y; B.pz = apex.z;
+    B.ax = (double)ax; B.ay = (double)ay; B.az = (double)az;
+    B.cosT = (double)cosT; B.sinT = (double)sinT;
+    B.rho = (double)rho;
+    B.tmax = (double)tmax;
+    return B;
+}
+
+// Can the bounding sphere touch the bundle? (false => provably no intersection with t >= 0.)
+// Let (wa, perp) be the centre's axial / radial coordinates about the axis. The distance from the
+// centre to the cone's side is perp*cos(theta) - wa*sin(theta); the sphere (fattened by rho) can
+// touch the solid cone only if that is <= Re, it is not wholly behind the apex plane, and it
+// is within reach. Squares instead of square roots.
+DEVI bool bundle_touches(const Bundle &B, const DevBound &b) {
+    if (B.off) return true;
+    if (!(b.r < __builtin_inf())) return true;
+    const double Re = (b.r + B.rho) * 1.00001 + 1e-12;
+    const double wx = b.cx - B.px, wy = b.cy - B.py, wz = b.cz - B.pz;
+    const double d2 = wx * wx + wy * wy + wz * wz;
+    if (d2 <= Re * Re) return true;
+    const double wa = wx * B.ax + wy * B.ay + wz * B.az;
+    if (wa < -Re) return false;                       // wholly behind the apex plane (theta < 90 deg)
+    const double far = B.tmax + Re;
+    if (d2 > far * far) return false;                  // beyond the reach of every ray (inf*inf = inf: never)
+    // the axis is unit only to ~2e-6: take an upper bound of the axial coordinate on the right-hand
+    // side and a lower bound of perp^2 on the left, so the inequality can only err towards "keep"
+    const double rhs = Re + (wa + fabs(wa) * 1e-5) * B.sinT;
+    if (rhs < 0.) return false;
+    const double perp2 = d2 - wa * wa * 1.00001;
+    return !(perp2 * (B.cosT * B.cosT) > rhs * rhs);   // NaN-safe: keep the object unless provably far
+}
+
 // ---- wave-uniform object loop ------------------------------------------------------------
 // f(j, m, kind, prim) is called for objects j = 0..n-1 in insertion order (World::intersect,
 // shape.rs:679-681) and returns true while some lane of the wave still needs objects.
@@ -183,6 +318,18 @@ DEVI bool occludes(uint32_t kind, V3 o, V3 d, double dist) {
 // SRC_LDS1 : the whole table was staged into LDS once by stage_all(); no barriers.
 // SRC_LDSN : tiles of P.tile_cap objects staged by the whole workgroup; EVERY thread of the
 //            workgroup must call this the same number of times (barriers inside).
+// The World tables are passed as separate `const T *__restrict__` kernel arguments (not inside the
+// parameter struct): only then may the compiler treat them as read-only for the whole launch and
+// fetch wave-uniform records with scalar loads (s_load through the scalar cache into SGPRs)
+// instead of 64 identical vector loads.
+struct Tables {
+    const DevIsect *__restrict__ isect;
+    const uint32_t *__restrict__ kind;
+    const DevShade *__restrict__ shade;
+    const DevPrim *__restrict__ prim;
+    const DevBound *__restrict__ bound;
+};
+
 struct LdsView {
     double *m;      // [cap][12]
     double *prim;   // [cap][4]
@@ -197,21 +344,39 @@ DEVI LdsView lds_view(double *base, uint32_t cap) {
     return v;
 }
 
-DEVI void stage_tile(const RenderParams &P, const LdsView &L, uint32_t base, uint32_t cnt) {
-    const double *gm = reinterpret_cast<const double *>(P.isect + base);
+DEVI void stage_tile(const Tables &T, const LdsView &L, uint32_t base, uint32_t cnt) {
+    const double *gm = reinterpret_cast<const double *>(T.isect + base);
     for (uint32_t e = threadIdx.x; e < cnt * 12; e += RTC_BLOCK) L.m[e] = gm[e];
-    const double *gp = reinterpret_cast<const double *>(P.prim + base);
+    const double *gp = reinterpret_cast<const double *>(T.prim + base);
     for (uint32_t e = threadIdx.x; e < cnt * 4; e += RTC_BLOCK) L.prim[e] = gp[e];
-    for (uint32_t e = threadIdx.x; e < cnt; e += RTC_BLOCK) L.kind[e] = P.kind[base + e];
+    for (uint32_t e = threadIdx.x; e < cnt; e += RTC_BLOCK) L.kind[e] = T.kind[base + e];
 }
 
 template <int SRC, class F>
-DEVI void for_each_object(const RenderParams &P, const LdsView &L, bool lane_needs, F &&f) {
-    if constexpr (SRC == SRC_SMEM) {
+DEVI void for_each_object(const RenderParams &P, const Tables &T, const LdsView &L, bool lane_needs, const Bundle &B, F &&f) {
+    if constexpr (SRC == SRC_CULL) {
+        // 64 objects at a time: each lane tests one object's bound against the wave's bundle; the
+        // ballot mask is walked in ascending object order (= insertion order, which the closest-hit
+        // tie-break relies on); survivors' records come through the scalar cache (uniform index).
+        if (ballot(lane_needs) == 0ull) return;
+        const uint32_t lane = threadIdx.x & 63u;
+        for (uint32_t base = 0; base < P.n; base += 64u) {
+            const uint32_t j = base + lane;
+            bool cand = false;
+            if (j < P.n) cand = bundle_touches(B, T.bound[j]);
+            unsigned long long mask = ballot(cand);
+            while (mask) {
+                const uint32_t jj = base + (uint32_t)__builtin_ctzll(mask);
+                mask &= mask - 1ull;
+                const DevIsect *rec = T.isect + jj;
+                if (!f((int)jj, rec->m, T.kind[jj], reinterpret_cast<const double *>(T.prim + jj))) return;
+            }
+        }
+    } else if constexpr (SRC == SRC_SMEM) {
         if (ballot(lane_needs) == 0ull) return;
         for (uint32_t j = 0; j < P.n; ++j) {
-            const DevIsect *rec = P.isect + j;
-            if (!f((int)j, rec->m, P.kind[j], reinterpret_cast<const double *>(P.prim + j))) break;
+            const DevIsect *rec = T.isect + j;
+            if (!f((int)j, rec->m, T.kind[j], reinterpret_cast<const double *>(T.prim + j))) break;
         }
     } else if constexpr (SRC == SRC_LDS1) {
         if (ballot(lane_needs) == 0ull) return;
@@ -224,7 +389,7 @@ DEVI void for_each_object(const RenderParams &P, const LdsView &L, bool lane_nee
         for (uint32_t base = 0; base < P.n; base += P.tile_cap) {
             const uint32_t cnt = (P.n - base < P.tile_cap) ? (P.n - base) : P.tile_cap;
             __syncthreads(); // previous tile fully consumed
-            stage_tile(P, L, base, cnt);
+            stage_tile(T, L, base, cnt);
             __syncthreads();
             if (wave_live) {
                 for (uint32_t j = 0; j < cnt; ++j) {
@@ -316,9 +481,13 @@ DEVI V3 combine(V3 surface, V3 reflected, V3 refracted, bool schlick, double R) 
 
 // ---- the kernel -------------------------------------------------------------------------
 template <int SRC, bool REFL, bool REFR>
-__global__ void __launch_bounds__(RTC_BLOCK) k_trace(const RenderParams P) {
+__global__ void __launch_bounds__(RTC_BLOCK)
+k_trace(const RenderParams P, const DevIsect *__restrict__ t_isect, const uint32_t *__restrict__ t_kind,
+        const DevShade *__restrict__ t_shade, const DevPrim *__restrict__ t_prim, const DevBound *__restrict__ t_bound) {
     extern __shared__ double lds_raw[];
     const LdsView L = lds_view(lds_raw, P.tile_cap);
+    Tables T;
+    T.isect = t_isect; T.kind = t_kind; T.shade = t_shade; T.prim = t_prim; T.bound = t_bound;
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -348,7 +517,7 @@ __global__ void __launch_bounds__(RTC_BLOCK) k_trace(const RenderParams P) {
     }
 
     if constexpr (SRC == SRC_LDS1) {
-        stage_tile(P, L, 0, P.n);
+        stage_tile(T, L, 0, P.n);
         __syncthreads();
     }
 
@@ -401,8 +570,14 @@ __global__ void __launch_bounds__(RTC_BLOCK) k_trace(const RenderParams P) {
             // ---- World::intersect + get_hit (shape.rs:677-683, 220-232), streaming form ----
             double best = __builtin_inf();
             int hidx = -1, hroot = 0;
-            if (shared_origin && first) {
-                for_each_object<SRC>(P, L, tracing, [&](int j, auto m, uint32_t kind, auto pr) {
+            Bundle B;
+            B.off = true;
+            if constexpr (SRC == SRC_CULL) {
+                if (ballot(tracing) != 0ull)
+                    B = make_bundle(tracing, shared_origin && first, cam_origin, ro, rd, __builtin_inf());
+            }
+            if (SRC != SRC_CULL && shared_origin && first) {
+                for_each_object<SRC>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
                     if (tracing) {
                         const V3 o = mk(pr[0], pr[1], pr[2]);
                         const V3 d = xvector(m, rd);
@@ -411,7 +586,7 @@ __global__ void __launch_bounds__(RTC_BLOCK) k_trace(const RenderParams P) {
                     return true;
                 });
             } else {
-                for_each_object<SRC>(P, L, tracing, [&](int j, auto m, uint32_t kind, auto pr) {
+                for_each_object<SRC>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
                     if (tracing) {
                         const V3 o = xpoint(m, ro);
                         const V3 d = xvector(m, rd);
@@ -427,8 +602,8 @@ __global__ void __launch_bounds__(RTC_BLOCK) k_trace(const RenderParams P) {
                reflectv = mk(0, 0, 0), sdir = mk(0, 0, 0);
             double sdist = 0., n1 = 1.0, n2 = 1.0, m_kr = 0., m_tr = 0.;
             bool inside = false;
-            const DevShade *S = P.shade + (hit ? hidx : 0);
-            const double *m_obj = P.isect[hit ? hidx : 0].m;
+            const DevShade *S = T.shade + (hit ? hidx : 0);
+            const double *m_obj = T.isect[hit ? hidx : 0].m;
             if (hit) {
                 point = vadd(ro, vmul(rd, best)); // Ray::position vec.rs:207-209
                 eyev = vneg(rd);
@@ -469,7 +644,9 @@ __global__ void __launch_bounds__(RTC_BLOCK) k_trace(const RenderParams P) {
                     bool have_all = false, have_oth = false;
                     double key_all = 0., key_oth = 0.;
                     int idx_all = -1, idx_oth = -1;
-                    for_each_object<SRC>(P, L, need, [&](int j, auto m, uint32_t kind, auto pr) {
+                    Bundle Ball; // entries with t < 0 matter here: visit every object
+                    Ball.off = true;
+                    for_each_object<SRC>(P, T, L, need, Ball, [&](int j, auto m, uint32_t kind, auto pr) {
                         if (need) {
                             const V3 o = xpoint(m, ro);
                             const V3 d = xvector(m, rd);
@@ -493,8 +670,8 @@ __global__ void __launch_bounds__(RTC_BLOCK) k_trace(const RenderParams P) {
                         return true;
                     });
                     if (need) {
-                        n1 = have_all ? P.shade[idx_all].refractive_index : 1.0;
-                        if (hroot == 1) n2 = have_oth ? P.shade[idx_oth].refractive_index : 1.0;
+                        n1 = have_all ? T.shade[idx_all].refractive_index : 1.0;
+                        if (hroot == 1) n2 = have_oth ? T.shade[idx_oth].refractive_index : 1.0;
                         else n2 = S->refractive_index;
                     }
                 }
@@ -503,7 +680,13 @@ __global__ void __launch_bounds__(RTC_BLOCK) k_trace(const RenderParams P) {
             // ---- is_shadowed (shape.rs:712-727): any-hit with early exit ----------------------
             bool sh_pending = hit, shadowed = false;
             c_shadow += popc64(ballot(hit));
-            for_each_object<SRC>(P, L, sh_pending, [&](int j, auto m, uint32_t kind, auto pr) {
+            Bundle Bs;
+            Bs.off = true;
+            if constexpr (SRC == SRC_CULL) {
+                // the segment over_point -> light, walked from the light: apex = light (shared)
+                if (ballot(hit) != 0ull) Bs = make_bundle(hit, true, lightp, lightp, vneg(sdir), sdist);
+            }
+            for_each_object<SRC>(P, T, L, sh_pending, Bs, [&](int j, auto m, uint32_t kind, auto pr) {
                 if (sh_pending) {
                     const V3 o = xpoint(m, over);
                     const V3 d = xvector(m, sdir);
@@ -635,11 +818,12 @@ __global__ void __launch_bounds__(RTC_BLOCK) k_trace(const RenderParams P) {
     if (P.counters) {
         const uint32_t npix = popc64(ballot(traced));
         if (lane == 0) {
-            if (c_primary) atomicAdd(P.counters + CNT_PRIMARY, (unsigned long long)c_primary);
-            if (c_shadow) atomicAdd(P.counters + CNT_SHADOW, (unsigned long long)c_shadow);
-            if (c_reflect) atomicAdd(P.counters + CNT_REFLECT, (unsigned long long)c_reflect);
-            if (c_refract) atomicAdd(P.counters + CNT_REFRACT, (unsigned long long)c_refract);
-            if (npix) atomicAdd(P.counters + CNT_PIXELS, (unsigned long long)npix);
+            unsigned long long *slot = P.counters + (size_t)((blockIdx.x * 4u + wave) % CNT_SLOTS) * CNT_N;
+            if (c_primary) atomicAdd(slot + CNT_PRIMARY, (unsigned long long)c_primary);
+            if (c_shadow) atomicAdd(slot + CNT_SHADOW, (unsigned long long)c_shadow);
+            if (c_reflect) atomicAdd(slot + CNT_REFLECT, (unsigned long long)c_reflect);
+            if (c_refract) atomicAdd(slot + CNT_REFRACT, (unsigned long long)c_refract);
+            if (npix) atomicAdd(slot + CNT_PIXELS, (unsigned long long)npix);
         }
     }
 }
@@ -684,7 +868,8 @@ static hipError_t launch_one(const RenderParams &P, dim3 grid, size_t lds_bytes,
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_trace<SRC, REFL, REFR>), grid, dim3(RTC_BLOCK), lds_bytes, stream, P);
+    hipLaunchKernelGGL((k_trace<SRC, REFL, REFR>), grid, dim3(RTC_BLOCK), lds_bytes, stream, P, P.isect, P.kind, P.shade, P.prim,
+                       P.bound);
     return hipGetLastError();
 }
 
@@ -700,6 +885,7 @@ extern "C" hipError_t rtc_launch_trace(const RenderParams *P, int src, int refl,
     RTC_CASE(SRC_SMEM)
     RTC_CASE(SRC_LDS1)
     RTC_CASE(SRC_LDSN)
+    RTC_CASE(SRC_CULL)
 #undef RTC_CASE
     return hipErrorInvalidValue;
 }

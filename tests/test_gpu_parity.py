@@ -43,7 +43,9 @@ def make_ctx(rtc, src=None, tile_cap=None):
                 os.environ[k] = v
 
 
-VARIANTS = [(None, None), (0, None), (1, None), (2, 16)]
+# None = the default (per-wave conservative cull); 0/1/2 = plain brute force with object records
+# through the scalar cache / one LDS tile / LDS tiles of 16 objects; 3 = cull, forced.
+VARIANTS = [(None, None), (0, None), (1, None), (2, 16), (3, None)]
 
 
 def camera_rays(rtc, cam, step=1):
@@ -185,6 +187,59 @@ def test_render_parity_all_scenes(rtc, O, scenes, src, tile_cap):
             dw.close()
     finally:
         ctx.close()
+
+
+def adversarial_scene(rtc, seed):
+    """Scenes built to stress the cull's conservativeness: tiny far spheres, huge near ones, thin
+    sheared ellipsoids, cubes, objects around and behind the camera and the light, the camera and
+    the light inside objects, mirrors and glass (wide secondary bundles)."""
+    rng = np.random.default_rng(seed)
+    u = lambda a, b: float(rng.uniform(a, b))
+    w = rtc.World(rtc.light((u(-6, 6), u(1, 9), u(-9, 2))))
+    n = int(rng.integers(3, 40))
+    for i in range(n):
+        k = int(rng.integers(0, 6))
+        if k == 0:   # tiny and far
+            t = rtc.Matrix.identity().scaling(*(3 * [u(0.01, 0.05)])).translation(u(-30, 30), u(0, 20), u(10, 90))
+        elif k == 1:  # huge, may contain camera or light
+            t = rtc.Matrix.identity().scaling(*(3 * [u(5, 30)])).translation(u(-10, 10), u(-10, 10), u(-10, 30))
+        elif k == 2:  # thin needle / pancake, rotated
+            t = (rtc.Matrix.identity().scaling(u(0.02, 0.1), u(1, 4), u(0.02, 2)).rotation_x(u(0, 3)).rotation_z(u(0, 3))
+                 .translation(u(-4, 4), u(0, 4), u(-2, 8)))
+        elif k == 3:  # sheared
+            t = (rtc.Matrix.identity().shearing(u(-1, 1), u(-1, 1), u(-1, 1), u(-1, 1), u(-1, 1), u(-1, 1)).scaling(u(0.3, 1.5), u(0.3, 1.5), u(0.3, 1.5))
+                 .translation(u(-4, 4), u(0, 3), u(-3, 8)))
+        elif k == 4:  # behind / beside the camera
+            t = rtc.Matrix.identity().scaling(*(3 * [u(0.3, 2)])).translation(u(-6, 6), u(-1, 4), u(-14, -4))
+        else:
+            t = rtc.Matrix.identity().scaling(*(3 * [u(0.2, 1.2)])).translation(u(-5, 5), u(0, 4), u(-3, 9))
+        glass = rng.random() < 0.25
+        mat = rtc.material(color=(u(0, 1), u(0, 1), u(0, 1)), ambient=u(0, 0.3), diffuse=u(0.2, 0.9), specular=u(0, 0.9),
+                           shininess=u(1, 300), reflective=(u(0.1, 0.9) if rng.random() < 0.4 else 0.0),
+                           transparency=(u(0.3, 1.0) if glass else 0.0), refractive_index=(u(1.05, 2.2) if glass else 1.0))
+        try:
+            w.add_shape((rtc.cube if rng.random() < 0.25 else rtc.sphere)(t, mat))
+        except rtc.RtcError:
+            pass  # singular by the reference's 1e-8 determinant rule: the reference would panic too
+    if rng.random() < 0.7:
+        w.add_shape(rtc.plane(rtc.Matrix.identity().rotation_z(u(-0.2, 0.2)).translation(0, u(-1, 0), 0),
+                              rtc.material(reflective=u(0, 0.5), specular=0.1, pattern=("checker", (0.3,) * 3, (0.7,) * 3, None))))
+    cam = rtc.camera(56, 40, u(0.4, 2.0), rtc.Matrix.make_view_transform((u(-3, 3), u(0.2, 4), u(-9, -3)), (u(-1, 1), u(0, 2), u(0, 4)), (0, 1, 0)))
+    return w, cam
+
+
+def test_cull_is_exact_on_adversarial_scenes(rtc, gpu, O):
+    """The conservative cull must never change a result: 40 random adversarial scenes, canvas and
+    ray counts against the oracle, and culled vs plain brute force (RTC_FLAG_NO_CULL = 1) bit for bit."""
+    for seed in range(40):
+        w, cam = adversarial_scene(rtc, 1000 + seed)
+        dw = gpu.upload(w)
+        got, st = dw.render(cam, rtc.MODE_RENDER_ASYNC, with_stats=True)
+        brute, sb = dw.render(cam, rtc.MODE_RENDER_ASYNC, flags=1, with_stats=True)
+        assert np.array_equal(got, brute) and st == sb, seed
+        want, ost = O.render(w.array(), len(w), w.light, cam, mode=1, nthreads=8, want_stats=True)
+        assert np.max(np.abs(got - want)) <= TIGHT_TOL and st == ost, seed
+        dw.close()
 
 
 def test_jamis_scene_config1(rtc, gpu, O):
