@@ -33,8 +33,8 @@ FP64_PEAK_TINSTR = 39.3      # 78.6 TFLOP/s FP64 vector counts FMA as 2; contrac
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--spheres", type=int, default=100)
@@ -42,6 +42,9 @@ def parse():
     ap.add_argument("--reflective", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (bounded sample)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo is a rehearsal aid for boxes with fewer GPUs than ranks (tiles hop through host memory)")
+    ap.add_argument("--no-overlap", action="store_true", help="wait for each gather before rendering the next frame")
     return ap.parse_args()
 
 
@@ -72,11 +75,16 @@ def main():
             sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback for the render path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a full node
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    gloo = args.dist_backend == "gloo"
     if world_size > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        if gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
 
     from _bootstrap import package
     rtc = package()
@@ -90,22 +98,45 @@ def main():
 
     # launch on torch's current stream so that torch events and RCCL order against the kernels
     stream = torch.cuda.current_stream(dev)
-    ctx = rtc.Context(local_rank, stream=stream.cuda_stream)
+    ctx = rtc.Context(dev_index, stream=stream.cuda_stream)
     dworld = ctx.upload(world)
-    tile = torch.zeros((rows_max, W, 3), dtype=torch.float64, device=dev)
-    canvas = torch.empty((world_size * rows_max, W, 3), dtype=torch.float64, device=dev) if (rank == 0 and world_size > 1) else None
+    # two tile / canvas buffers: the RCCL gather of frame k runs (on RCCL's own stream) while frame
+    # k+1 renders; a buffer is reused only after the gather that reads or fills it has completed
+    nbuf = 1 if (world_size == 1 or args.no_overlap) else 2
+    gdev = torch.device("cpu") if gloo else dev
+    tile_bufs = [torch.zeros((rows_max, W, 3), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+    canvases = [torch.empty((world_size * rows_max, W, 3), dtype=torch.float64, device=gdev) for _ in range(nbuf)] \
+        if (rank == 0 and world_size > 1) else [None] * nbuf
+    pending = [None] * nbuf
+    state = {"k": 0}
 
     def step(ev=None):
+        b = state["k"] % nbuf
+        state["k"] += 1
+        if pending[b] is not None:
+            pending[b].wait()       # current stream waits for the gather that last used buffer b
+            pending[b] = None
+        tile = tile_bufs[b]
         if ev:
             ev[0].record(stream)
         dworld.render_rows(cam, y0, y1, tile.data_ptr(), rtc.MODE_RENDER_ASYNC)
         if ev:
             ev[1].record(stream)
         if world_size > 1:
-            tiles.gather_tiles(tile, canvas, world_size, rank)
+            src = tile.cpu() if gloo else tile
+            work = tiles.gather_tiles(src, canvases[b], world_size, rank, async_op=not args.no_overlap)
+            if work is not None:
+                pending[b] = work
+
+    def drain():
+        for b in range(nbuf):
+            if pending[b] is not None:
+                pending[b].wait()
+                pending[b] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     ctx.reset_stats()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world_size > 1:
@@ -114,6 +145,7 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(events[k])
+    drain()
     torch.cuda.synchronize(dev)
     if world_size > 1:
         dist.barrier()
@@ -123,7 +155,7 @@ def main():
     kernel_ms = sum(a.elapsed_time(b) for a, b in events) / max(1, args.steps)
     last_ms = ctx.last_kernel_ms()
     agg = torch.tensor([elapsed, float(st["rays_primary"]), float(st["rays_shadow"]), float(st["rays_reflect"] + st["rays_refract"]),
-                        kernel_ms], dtype=torch.float64, device=dev)
+                        kernel_ms], dtype=torch.float64, device=torch.device("cpu") if gloo else dev)
     if world_size > 1:
         tmax = agg[[0, 4]].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -158,7 +190,8 @@ def main():
             "config": {
                 "workload": f"{W}x{H}, {args.spheres} spheres" + ("" if args.no_plane else " + checker floor plane") +
                             ", 1 point light, render_async, SplitMix64 seed 13" + (", reflective depth 5" if args.reflective else ""),
-                "objects": len(world), "rows_per_gpu": rows, "parallelism": f"row-tiles x{world_size} + RCCL gather" if world_size > 1 else "single GPU",
+                "objects": len(world), "rows_per_gpu": rows, "parallelism": (f"row-tiles x{world_size} + {'gloo (rehearsal)' if gloo else 'RCCL'} gather to rank 0"
+                                                                          + ("" if args.no_overlap else ", gather k overlapped with render k+1")) if world_size > 1 else "single GPU",
                 "rays_per_frame_primary_shadow": int(round(rays_ps / steps)), "rays_per_frame_other": int(round(rays_other / steps)),
             },
             "roofline": {

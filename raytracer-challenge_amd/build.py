@@ -19,6 +19,7 @@ LIB = PKG / "librtc.so"
 
 SOURCES = ["host_math.cpp", "host_ppm.cpp", "host_yaml.cpp", "rtc_api.cpp", "rtc_kernels.hip"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
+COMMON += os.environ.get("RTC_CXXFLAGS", "").split()  # experiments, e.g. -DRTC_WAVES_PER_SIMD=4
 
 
 def hipcc() -> str:

@@ -27,6 +27,9 @@
 
 #define RTC_BLOCK 256
 #define RTC_MAX_STACK 8
+#ifndef RTC_WAVES_PER_SIMD
+#define RTC_WAVES_PER_SIMD 2 // 2nd argument of __launch_bounds__: minimum waves per SIMD (caps VGPRs)
+#endif
 
 enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2, SRC_CULL = 3 };
 
@@ -223,6 +226,13 @@ struct Bundle {
     bool off;            // bundle could not be bounded: every object is a candidate
 };
 
+// A wave-uniform double that the compiler would otherwise keep in two VGPRs: move it to SGPRs.
+DEVI double uniform_f64(double x) {
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 DEVI bool finite3(V3 v) { return fabs(v.x) < __builtin_inf() && fabs(v.y) < __builtin_inf() && fabs(v.z) < __builtin_inf(); }
 
 // apex_shared: every active lane's ray starts at `apex` (camera origin, or the light for shadow
@@ -279,11 +289,11 @@ DEVI Bundle make_bundle(bool active, bool apex_shared, V3 apex, V3 o, V3 d, doub
         sinT = __builtin_sqrtf(fmaxf(0.f, 1.f - cosT * cosT)) + 1e-3f;
     }
     if (!(sinT < 0.98f)) B.off = true;
-    B.px = apex.x; B.py = apex.y; B.pz = apex.z;
-    B.ax = (double)ax; B.ay = (double)ay; B.az = (double)az;
-    B.cosT = (double)cosT; B.sinT = (double)sinT;
-    B.rho = (double)rho;
-    B.tmax = (double)tmax;
+    B.px = uniform_f64(apex.x); B.py = uniform_f64(apex.y); B.pz = uniform_f64(apex.z);
+    B.ax = uniform_f64((double)ax); B.ay = uniform_f64((double)ay); B.az = uniform_f64((double)az);
+    B.cosT = uniform_f64((double)cosT); B.sinT = uniform_f64((double)sinT);
+    B.rho = uniform_f64((double)rho);
+    B.tmax = uniform_f64((double)tmax);
     return B;
 }
 
@@ -480,8 +490,10 @@ DEVI V3 combine(V3 surface, V3 reflected, V3 refracted, bool schlick, double R) 
 }
 
 // ---- the kernel -------------------------------------------------------------------------
-template <int SRC, bool REFL, bool REFR>
-__global__ void __launch_bounds__(RTC_BLOCK)
+// PROBE = true is the rtc_color_at flavour (arbitrary rays in, colours + hit records out); the
+// render flavour (PROBE = false) never carries the hit record's extra vectors in registers.
+template <int SRC, bool REFL, bool REFR, bool PROBE>
+__global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD)
 k_trace(const RenderParams P, const DevIsect *__restrict__ t_isect, const uint32_t *__restrict__ t_kind,
         const DevShade *__restrict__ t_shade, const DevPrim *__restrict__ t_prim, const DevBound *__restrict__ t_bound) {
     extern __shared__ double lds_raw[];
@@ -491,7 +503,7 @@ k_trace(const RenderParams P, const DevIsect *__restrict__ t_isect, const uint32
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    const bool probe = P.rays != nullptr;
+    constexpr bool probe = PROBE;
 
     // XCD-aware remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs;
     // give each XCD a contiguous run of logical tiles (bijective for any grid size).
@@ -695,7 +707,7 @@ k_trace(const RenderParams P, const DevIsect *__restrict__ t_isect, const uint32
                 return ballot(sh_pending) != 0ull;
             });
 
-            if (probe && first && in_range && P.hits) {
+            if constexpr (PROBE) if (first && in_range && P.hits) {
                 rtc_hit *H = reinterpret_cast<rtc_hit *>(P.hits) + ray_index;
                 H->hit_index = hit ? hidx : -1;
                 H->inside = inside ? 1u : 0u;
@@ -861,16 +873,21 @@ __global__ void k_arith(uint32_t op, const double *a, const double *b, uint32_t 
 }
 
 // ---- launchers (called from rtc_api.cpp) --------------------------------------------------
-template <int SRC, bool REFL, bool REFR>
-static hipError_t launch_one(const RenderParams &P, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+template <int SRC, bool REFL, bool REFR, bool PROBE>
+static hipError_t launch_kernel(const RenderParams &P, dim3 grid, size_t lds_bytes, hipStream_t stream) {
     if (lds_bytes > 48 * 1024) { // more dynamic LDS than the default limit: opt in (up to 160 KiB per CU on gfx950)
-        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace<SRC, REFL, REFR>),
+        const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace<SRC, REFL, REFR, PROBE>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_trace<SRC, REFL, REFR>), grid, dim3(RTC_BLOCK), lds_bytes, stream, P, P.isect, P.kind, P.shade, P.prim,
-                       P.bound);
+    hipLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK), lds_bytes, stream, P, P.isect, P.kind, P.shade,
+                       P.prim, P.bound);
     return hipGetLastError();
+}
+template <int SRC, bool REFL, bool REFR>
+static hipError_t launch_one(const RenderParams &P, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+    if (P.rays != nullptr) return launch_kernel<SRC, REFL, REFR, true>(P, grid, lds_bytes, stream);
+    return launch_kernel<SRC, REFL, REFR, false>(P, grid, lds_bytes, stream);
 }
 
 extern "C" hipError_t rtc_launch_trace(const RenderParams *P, int src, int refl, int refr, uint32_t nblocks,

@@ -19,15 +19,15 @@ def row_range(height: int, world_size: int, rank: int) -> tuple[int, int]:
     return y0, min(height, y0 + per)
 
 
-def gather_tiles(tile, canvas, world_size: int, rank: int, group=None) -> None:
+def gather_tiles(tile, canvas, world_size: int, rank: int, group=None, async_op: bool = False):
     """Gather every rank's (rows_per_rank, W, 3) tile into `canvas` ((world_size*rows_per_rank, W, 3))
-    on rank 0. Bands are contiguous, so the gather lands each tile at its final place."""
+    on rank 0. Bands are contiguous, so the gather lands each tile at its final place. With
+    async_op=True returns the work handle (wait() before reusing `tile` / reading `canvas`)."""
     import torch.distributed as dist
 
     if rank == 0:
-        dist.gather(tile, list(canvas.chunk(world_size, dim=0)), dst=0, group=group)
-    else:
-        dist.gather(tile, None, dst=0, group=group)
+        return dist.gather(tile, list(canvas.chunk(world_size, dim=0)), dst=0, group=group, async_op=async_op)
+    return dist.gather(tile, None, dst=0, group=group, async_op=async_op)
 
 
 def assemble(canvas, height: int):
