@@ -397,6 +397,21 @@ rtc_status rtc_stats_read(rtc_context *ctx, rtc_stats *out) {
     return RTC_OK;
 }
 
+// Diagnostic: the raw replicated counter block summed over replicas (CNT_N values); not part of
+// include/rtc.h. Used by tools/phase_shares.py with a -DRTC_STAMPS build.
+extern "C" rtc_status rtc_debug_counters(rtc_context *ctx, unsigned long long *out, uint32_t n) {
+    if (!ctx || !out) return RTC_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<unsigned long long> slots((size_t)CNT_N * CNT_SLOTS);
+    HIP_TRY(hipMemcpyAsync(slots.data(), ctx->d_counters, sizeof(unsigned long long) * slots.size(), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (uint32_t k = 0; k < n && k < CNT_N; ++k) {
+        out[k] = 0;
+        for (int sl = 0; sl < CNT_SLOTS; ++sl) out[k] += slots[(size_t)sl * CNT_N + k];
+    }
+    return RTC_OK;
+}
+
 rtc_status rtc_stats_reset(rtc_context *ctx) {
     if (!ctx) return RTC_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));

@@ -27,8 +27,14 @@
 
 #define RTC_BLOCK 256
 #define RTC_MAX_STACK 8
+// 2nd argument of __launch_bounds__ = minimum waves per SIMD (caps VGPRs: 3 -> 168, 2 -> 256).
+// Measured on the north-star scene (culled flat kernel): 2 -> 0.171 ms, 3 -> 0.139 ms, 4 -> 0.159 ms
+// (4 spills). Kernels that carry the reflection/refraction frame stack keep 2.
 #ifndef RTC_WAVES_PER_SIMD
-#define RTC_WAVES_PER_SIMD 2 // 2nd argument of __launch_bounds__: minimum waves per SIMD (caps VGPRs)
+#define RTC_WAVES_PER_SIMD 3
+#endif
+#ifndef RTC_WAVES_PER_SIMD_STACK
+#define RTC_WAVES_PER_SIMD_STACK 2
 #endif
 
 enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2, SRC_CULL = 3 };
@@ -38,6 +44,15 @@ struct V3 {
 };
 
 #define DEVI __device__ __forceinline__
+
+// Diagnostic build only (-DRTC_STAMPS): s_memtime stamps around the phases of k_trace, summed per
+// phase into counters CNT_STAMP0.. (read with rtc_debug_counters). Never enabled in the shipped
+// library; the stamped build's run time is not meaningful, only the shares are.
+#ifdef RTC_STAMPS
+#define STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp_t[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 DEVI V3 mk(double x, double y, double z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
 DEVI V3 vadd(V3 a, V3 b) { return mk(a.x + b.x, a.y + b.y, a.z + b.z); }
@@ -131,6 +146,14 @@ template <bool HAVE_C> DEVI int shape_entries(uint32_t kind, V3 o, V3 d, double 
 // sorted list == smallest t >= 0.0, ties to the entry inserted first (lower object index, then
 // first root). For a sphere t1 <= t2, so the second root is only needed when the first is not
 // a candidate (t1 < 0 or NaN).
+// Object-space y row only: all a plane needs (transform.rs:116,125 for the y component).
+template <class P> DEVI double xpoint_y(P m, V3 p) { return m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7]; }
+template <class P> DEVI double xvector_y(P m, V3 v) { return m[4] * v.x + m[5] * v.y + m[6] * v.z; }
+
+// World-space ray in, per-kind transform inside (a plane only needs the y row of the inverse).
+template <class P> DEVI void closest_world(uint32_t kind, P m, V3 ro, V3 rd, int j, double &best, int &hidx, int &hroot);
+template <class P> DEVI bool occludes_world(uint32_t kind, P m, V3 ro, V3 rd, double dist);
+
 template <bool HAVE_C>
 DEVI void closest_update(uint32_t kind, V3 o, V3 d, double c_pre, int j, double &best, int &hidx, int &hroot) {
     if (kind == RTC_SPHERE) {
@@ -179,6 +202,27 @@ DEVI bool occludes(uint32_t kind, V3 o, V3 d, double dist) {
     return false;
 }
 
+template <class P> DEVI void closest_world(uint32_t kind, P m, V3 ro, V3 rd, int j, double &best, int &hidx, int &hroot) {
+    if (kind == RTC_PLANE) { // shape.rs:462-471
+        const double oy = xpoint_y(m, ro), dy = xvector_y(m, rd);
+        if (!(fabs(dy) < RTC_EPSILON)) {
+            const double t = -oy / dy;
+            if (t >= 0.0 && t < best) { best = t; hidx = j; hroot = 0; }
+        }
+    } else {
+        closest_update<false>(kind, xpoint(m, ro), xvector(m, rd), 0., j, best, hidx, hroot);
+    }
+}
+template <class P> DEVI bool occludes_world(uint32_t kind, P m, V3 ro, V3 rd, double dist) {
+    if (kind == RTC_PLANE) {
+        const double oy = xpoint_y(m, ro), dy = xvector_y(m, rd);
+        if (fabs(dy) < RTC_EPSILON) return false;
+        const double t = -oy / dy;
+        return t >= 0.0 && t < dist;
+    }
+    return occludes(kind, xpoint(m, ro), xvector(m, rd), dist);
+}
+
 // ---- wave64 reductions (DPP): inclusive scan inside each row of 16 lanes, then two row
 // broadcasts; the total lands in lane 63. All 64 lanes must execute these (converged code);
 // lanes that do not take part pass the identity.
@@ -196,17 +240,21 @@ DEVI float wave_sum(float v) {
     v += dpp_f32<0x143, 0xc>(0.f, v); // row_bcast:31 into rows 2,3
     return lane63(v);
 }
-DEVI float wave_max(float v) { // v >= 0 or any finite; identity -inf
-    const float id = -__builtin_inff();
-    v = fmaxf(v, dpp_f32<0x111, 0xf>(id, v));
-    v = fmaxf(v, dpp_f32<0x112, 0xf>(id, v));
-    v = fmaxf(v, dpp_f32<0x114, 0xf>(id, v));
-    v = fmaxf(v, dpp_f32<0x118, 0xf>(id, v));
-    v = fmaxf(v, dpp_f32<0x142, 0xa>(id, v));
-    v = fmaxf(v, dpp_f32<0x143, 0xc>(id, v));
-    return lane63(v);
+// Maximum of NON-NEGATIVE floats (NaN-free): their bit patterns order like unsigned integers, and
+// v_max_u32 with identity 0 folds into the DPP instruction (one instruction per step).
+template <int CTRL, int ROW_MASK> DEVI unsigned dpp_u32(unsigned src) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)src, CTRL, ROW_MASK, 0xf, false);
 }
-DEVI float wave_min(float v) { return -wave_max(-v); }
+DEVI float wave_max_nonneg(float f) {
+    unsigned v = __builtin_bit_cast(unsigned, f);
+    v = max(v, dpp_u32<0x111, 0xf>(v));
+    v = max(v, dpp_u32<0x112, 0xf>(v));
+    v = max(v, dpp_u32<0x114, 0xf>(v));
+    v = max(v, dpp_u32<0x118, 0xf>(v));
+    v = max(v, dpp_u32<0x142, 0xa>(v));
+    v = max(v, dpp_u32<0x143, 0xc>(v));
+    return __builtin_bit_cast(float, (unsigned)__builtin_amdgcn_readlane((int)v, 63));
+}
 
 // ---- conservative per-wave cull ------------------------------------------------------------
 // The rays a wave is about to trace form a bundle: a cone (apex, unit axis, half-angle theta)
@@ -235,51 +283,59 @@ DEVI double uniform_f64(double x) {
 
 DEVI bool finite3(V3 v) { return fabs(v.x) < __builtin_inf() && fabs(v.y) < __builtin_inf() && fabs(v.z) < __builtin_inf(); }
 
-// apex_shared: every active lane's ray starts at `apex` (camera origin, or the light for shadow
-// segments walked backwards); otherwise the apex is the centroid of the lanes' origins.
-DEVI Bundle make_bundle(bool active, bool apex_shared, V3 apex, V3 o, V3 d, double reach) {
+// SHARED: every active lane's ray starts at `apex` (the camera origin, or the light for shadow
+// segments walked backwards); otherwise the apex is the centroid of the lanes' origins and `rho`
+// their spread. REACH: the rays end after `reach` (shadow segments). The axis is simply the
+// direction of the first active lane (no reduction needed); the half-angle is the largest
+// deviation from it.
+template <bool SHARED, bool REACH>
+DEVI Bundle make_bundle(bool active, V3 apex, V3 o, V3 d, double reach) {
     Bundle B;
-    bool bad = active && !(finite3(o) && finite3(d) && (d.x != 0. || d.y != 0. || d.z != 0.));
     float fx = 0.f, fy = 0.f, fz = 0.f;
-    if (active && !bad) {
+    bool good = active && finite3(o) && finite3(d);
+    if (good) {
         const float x = (float)d.x, y = (float)d.y, z = (float)d.z;
         const float l2 = x * x + y * y + z * z;
-        if (l2 > 1e-30f && l2 < 1e30f) {
-            const float il = __builtin_amdgcn_rsqf(l2);
-            fx = x * il; fy = y * il; fz = z * il;
-        } else bad = true;
+        good = l2 > 1e-30f && l2 < 1e30f;
+        const float il = __builtin_amdgcn_rsqf(l2);
+        fx = x * il; fy = y * il; fz = z * il;
     }
-    const float sx = wave_sum(fx), sy = wave_sum(fy), sz = wave_sum(fz);
-    const float s2 = sx * sx + sy * sy + sz * sz;
-    const float is = __builtin_amdgcn_rsqf(fmaxf(s2, 1e-20f));
-    const float ax = sx * is, ay = sy * is, az = sz * is;
-    float c = 1.f, q2 = 0.f;
-    if (active && !bad) {
-        c = ax * fx + ay * fy + az * fz;
+    const unsigned long long gmask = ballot(good);
+    bool off = ballot(active && !good) != 0ull || gmask == 0ull;
+    const int lane0 = gmask ? __builtin_ctzll(gmask) : 0;
+    const float ax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), lane0));
+    const float ay = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy), lane0));
+    const float az = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fz), lane0));
+    float omc = 0.f, q2 = 0.f; // 1 - cos and sin^2 of the angle to the axis
+    if (good) {
+        omc = fmaxf(0.f, 1.f - (ax * fx + ay * fy + az * fz));
         const float cx = ay * fz - az * fy, cy = az * fx - ax * fz, cz = ax * fy - ay * fx;
         q2 = cx * cx + cy * cy + cz * cz;
     }
-    const float cmin = wave_min(c), q2max = wave_max(q2);
+    const float cmin = 1.f - wave_max_nonneg(omc), q2max = wave_max_nonneg(q2);
     float rho = 0.f;
-    if (!apex_shared) {
-        const float cnt = wave_sum(active ? 1.f : 0.f);
-        const float mx = wave_sum(active ? (float)o.x : 0.f) / fmaxf(cnt, 1.f);
-        const float my = wave_sum(active ? (float)o.y : 0.f) / fmaxf(cnt, 1.f);
-        const float mz = wave_sum(active ? (float)o.z : 0.f) / fmaxf(cnt, 1.f);
+    if constexpr (!SHARED) {
+        const float cnt = fmaxf(wave_sum(good ? 1.f : 0.f), 1.f);
+        const float mx = wave_sum(good ? (float)o.x : 0.f) / cnt;
+        const float my = wave_sum(good ? (float)o.y : 0.f) / cnt;
+        const float mz = wave_sum(good ? (float)o.z : 0.f) / cnt;
         apex = mk((double)mx, (double)my, (double)mz);
         float e2 = 0.f;
-        if (active && !bad) {
+        if (good) {
             const double ex = o.x - apex.x, ey = o.y - apex.y, ez = o.z - apex.z;
             e2 = (float)(ex * ex + ey * ey + ez * ez) * 1.0001f;
-            if (!(e2 < 1e30f)) bad = true;
         }
-        rho = __builtin_sqrtf(wave_max(e2)) * 1.0001f + 1e-30f;
-        if (!(fabsf(mx) < 1e30f && fabsf(my) < 1e30f && fabsf(mz) < 1e30f)) bad = true;
+        const float e2max = wave_max_nonneg(e2);
+        rho = __builtin_sqrtf(e2max) * 1.0001f + 1e-30f;
+        if (!(e2max < 1e30f) || !(fabsf(mx) < 1e30f && fabsf(my) < 1e30f && fabsf(mz) < 1e30f)) off = true;
     }
-    float tm = 0.f;
-    if (active) tm = (reach < 1e30) ? (float)reach * 1.0001f + 1e-30f : __builtin_inff();
-    const float tmax = wave_max(tm);
-    B.off = (ballot(bad) != 0ull) || !(s2 > 1e-6f) || !(cmin > 0.2f);
+    float tmax = __builtin_inff();
+    if constexpr (REACH) {
+        float tm = 0.f;
+        if (good) tm = (reach < 1e30) ? fmaxf(0.f, (float)reach) * 1.0001f + 1e-30f : __builtin_inff();
+        tmax = wave_max_nonneg(tm);
+    }
+    if (!(cmin > 0.2f)) off = true;
     float sinT, cosT;
     if (cmin > 0.7f) { // narrow bundle: the cross product resolves small angles, the dot does not
         sinT = __builtin_sqrtf(q2max) * 1.001f + 4e-6f;
@@ -288,7 +344,8 @@ DEVI Bundle make_bundle(bool active, bool apex_shared, V3 apex, V3 o, V3 d, doub
         cosT = cmin - 1e-3f;
         sinT = __builtin_sqrtf(fmaxf(0.f, 1.f - cosT * cosT)) + 1e-3f;
     }
-    if (!(sinT < 0.98f)) B.off = true;
+    if (!(sinT < 0.98f)) off = true;
+    B.off = off;
     B.px = uniform_f64(apex.x); B.py = uniform_f64(apex.y); B.pz = uniform_f64(apex.z);
     B.ax = uniform_f64((double)ax); B.ay = uniform_f64((double)ay); B.az = uniform_f64((double)az);
     B.cosT = uniform_f64((double)cosT); B.sinT = uniform_f64((double)sinT);
@@ -362,8 +419,8 @@ DEVI void stage_tile(const Tables &T, const LdsView &L, uint32_t base, uint32_t 
     for (uint32_t e = threadIdx.x; e < cnt; e += RTC_BLOCK) L.kind[e] = T.kind[base + e];
 }
 
-template <int SRC, class F>
-DEVI void for_each_object(const RenderParams &P, const Tables &T, const LdsView &L, bool lane_needs, const Bundle &B, F &&f) {
+template <int SRC, class PP, class F>
+DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool lane_needs, const Bundle &B, F &&f) {
     if constexpr (SRC == SRC_CULL) {
         // 64 objects at a time: each lane tests one object's bound against the wave's bundle; the
         // ballot mask is walked in ascending object order (= insertion order, which the closest-hit
@@ -434,7 +491,8 @@ DEVI V3 pattern_color(const DevShade *S, const double *m_obj, V3 world_point) {
 
 // Material::lighting material.rs:319-361. lightv = (light.position - point).normalize() is
 // the shadow ray's direction (same expression, shape.rs:717-719), passed in.
-DEVI V3 lighting(const RenderParams &P, const DevShade *S, const double *m_obj, V3 point, V3 eyev, V3 normal,
+template <class PP>
+DEVI V3 lighting(const PP &P, const DevShade *S, const double *m_obj, V3 point, V3 eyev, V3 normal,
                  V3 lightv, bool in_shadow) {
     const V3 I = mk(P.light_int[0], P.light_int[1], P.light_int[2]);
     const V3 base = (S->pattern_kind != RTC_PATTERN_NONE) ? pattern_color(S, m_obj, point)
@@ -472,6 +530,19 @@ DEVI double reflectance(V3 eyev, V3 normal, double n1, double n2) {
     return r0 + (1.0 - r0) * (x * (x2 * x2)); // powi(5)
 }
 
+// The parameter block lives in the kernarg segment. Its loads are invariant, so LLVM hoists every
+// one of them to the kernel entry and then has to carry ~80 SGPRs through the whole kernel (they
+// spill into VGPR lanes). KP(P_arg) hands out a fresh, opaque constant-address-space view of the
+// same block; loads through it stay in the phase that asked for it.
+// (RenderParams is the kernel's FIRST argument, i.e. offset 0 of the kernarg segment.)
+typedef const __attribute__((address_space(4))) RenderParams *ParamPtr;
+DEVI ParamPtr param_view() {
+    unsigned long long a = (unsigned long long)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(a));
+    return (ParamPtr)a;
+}
+#define KP(arg) (*param_view())
+
 struct Frame {
     V3 surface;
     V3 reflected;
@@ -493,10 +564,11 @@ DEVI V3 combine(V3 surface, V3 reflected, V3 refracted, bool schlick, double R) 
 // PROBE = true is the rtc_color_at flavour (arbitrary rays in, colours + hit records out); the
 // render flavour (PROBE = false) never carries the hit record's extra vectors in registers.
 template <int SRC, bool REFL, bool REFR, bool PROBE>
-__global__ void __launch_bounds__(RTC_BLOCK, RTC_WAVES_PER_SIMD)
-k_trace(const RenderParams P, const DevIsect *__restrict__ t_isect, const uint32_t *__restrict__ t_kind,
+__global__ void __launch_bounds__(RTC_BLOCK, (REFL ? RTC_WAVES_PER_SIMD_STACK : RTC_WAVES_PER_SIMD))
+k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const uint32_t *__restrict__ t_kind,
         const DevShade *__restrict__ t_shade, const DevPrim *__restrict__ t_prim, const DevBound *__restrict__ t_bound) {
     extern __shared__ double lds_raw[];
+    const auto &P = KP(P_arg); // set-up view: grid, sizes, mode
     const LdsView L = lds_view(lds_raw, P.tile_cap);
     Tables T;
     T.isect = t_isect; T.kind = t_kind; T.shade = t_shade; T.prim = t_prim; T.bound = t_bound;
@@ -533,14 +605,14 @@ k_trace(const RenderParams P, const DevIsect *__restrict__ t_isect, const uint32
         __syncthreads();
     }
 
-    const V3 lightp = mk(P.light_pos[0], P.light_pos[1], P.light_pos[2]);
-    // ray origin of every primary ray: transform_point(view_inv, (0,0,0)) camera.rs:72
-    const V3 cam_origin = xpoint(P.vinv, mk(0., 0., 0.));
 
     uint32_t c_primary = 0, c_shadow = 0, c_reflect = 0, c_refract = 0; // wave-uniform
+#ifdef RTC_STAMPS
+    unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    STAMP(0);
 
     const uint32_t nsamples = (probe || P.samples == 1u) ? 1u : 4u;
-    V3 acc = mk(0., 0., 0.); // Color::average_over running sums color.rs:128-136
     V3 result = mk(0., 0., 0.);
 
     Frame stack[REFL ? RTC_MAX_STACK : 1];
@@ -548,6 +620,9 @@ k_trace(const RenderParams P, const DevIsect *__restrict__ t_isect, const uint32
     for (uint32_t s = 0; s < nsamples; ++s) {
         V3 ro, rd;
         bool shared_origin;
+        const auto &Pr = KP(P_arg); // ray-generation view: camera block
+        // ray origin of every primary ray: transform_point(view_inv, (0,0,0)) camera.rs:72
+        const V3 cam_origin = xpoint(Pr.vinv, mk(0., 0., 0.));
         if (probe) {
             const double *rp = P.rays + (size_t)(in_range ? ray_index : 0u) * 6;
             ro = mk(rp[0], rp[1], rp[2]);
@@ -557,11 +632,11 @@ k_trace(const RenderParams P, const DevIsect *__restrict__ t_isect, const uint32
             // Camera::ray_for_pixel_offset camera.rs:64-76; sub-sample offsets camera.rs:98,102-105
             const double xo = (nsamples == 1u) ? 0.5 : ((s & 1u) ? 0.75 : 0.25);
             const double yo = (nsamples == 1u) ? 0.5 : ((s & 2u) ? 0.75 : 0.25);
-            const double xoffset = ((double)px + xo) * P.pixel_size;
-            const double yoffset = ((double)py + yo) * P.pixel_size;
-            const double world_x = P.half_width - xoffset;
-            const double world_y = P.half_height - yoffset;
-            const V3 pixel = xpoint(P.vinv, mk(world_x, world_y, -1.));
+            const double xoffset = ((double)px + xo) * Pr.pixel_size;
+            const double yoffset = ((double)py + yo) * Pr.pixel_size;
+            const double world_x = Pr.half_width - xoffset;
+            const double world_y = Pr.half_height - yoffset;
+            const V3 pixel = xpoint(Pr.vinv, mk(world_x, world_y, -1.));
             ro = cam_origin;
             rd = vnormalize(vsub(pixel, cam_origin));
             shared_origin = true;
@@ -579,15 +654,19 @@ k_trace(const RenderParams P, const DevIsect *__restrict__ t_isect, const uint32
             else any_tracing = ballot(tracing) != 0ull;
             if (!any_tracing) break;
 
+            STAMP(1); // ray generated
             // ---- World::intersect + get_hit (shape.rs:677-683, 220-232), streaming form ----
             double best = __builtin_inf();
             int hidx = -1, hroot = 0;
             Bundle B;
             B.off = true;
             if constexpr (SRC == SRC_CULL) {
-                if (ballot(tracing) != 0ull)
-                    B = make_bundle(tracing, shared_origin && first, cam_origin, ro, rd, __builtin_inf());
+                if (ballot(tracing) != 0ull) {
+                    if (shared_origin && first) B = make_bundle<true, false>(tracing, cam_origin, ro, rd, 0.);
+                    else B = make_bundle<false, false>(tracing, cam_origin, ro, rd, 0.);
+                }
             }
+            STAMP(2); // primary bundle built
             if (SRC != SRC_CULL && shared_origin && first) {
                 for_each_object<SRC>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
                     if (tracing) {
@@ -599,15 +678,14 @@ k_trace(const RenderParams P, const DevIsect *__restrict__ t_isect, const uint32
                 });
             } else {
                 for_each_object<SRC>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
-                    if (tracing) {
-                        const V3 o = xpoint(m, ro);
-                        const V3 d = xvector(m, rd);
-                        closest_update<false>(kind, o, d, 0., j, best, hidx, hroot);
-                    }
+                    if (tracing) closest_world(kind, m, ro, rd, j, best, hidx, hroot);
                     return true;
                 });
             }
             const bool hit = tracing && hidx >= 0;
+            STAMP(3); // closest hit found
+            const auto &Ph = KP(P_arg); // shading view: light
+            const V3 lightp = mk(Ph.light_pos[0], Ph.light_pos[1], Ph.light_pos[2]);
 
             // ---- Intersection::compute_vectors (shape.rs:144-152, 75-96) --------------------
             V3 point = mk(0, 0, 0), eyev = mk(0, 0, 0), normal = mk(0, 0, 0), over = mk(0, 0, 0), under = mk(0, 0, 0),
@@ -690,23 +768,27 @@ k_trace(const RenderParams P, const DevIsect *__restrict__ t_isect, const uint32
             }
 
             // ---- is_shadowed (shape.rs:712-727): any-hit with early exit ----------------------
+            STAMP(4); // hit record + shadow ray
             bool sh_pending = hit, shadowed = false;
             c_shadow += popc64(ballot(hit));
             Bundle Bs;
             Bs.off = true;
             if constexpr (SRC == SRC_CULL) {
                 // the segment over_point -> light, walked from the light: apex = light (shared)
-                if (ballot(hit) != 0ull) Bs = make_bundle(hit, true, lightp, lightp, vneg(sdir), sdist);
+                if (ballot(hit) != 0ull) Bs = make_bundle<true, true>(hit, lightp, lightp, vneg(sdir), sdist);
             }
+            STAMP(5); // shadow bundle built
             for_each_object<SRC>(P, T, L, sh_pending, Bs, [&](int j, auto m, uint32_t kind, auto pr) {
                 if (sh_pending) {
-                    const V3 o = xpoint(m, over);
-                    const V3 d = xvector(m, sdir);
-                    if (occludes(kind, o, d, sdist)) { shadowed = true; sh_pending = false; }
+                    if (occludes_world(kind, m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
                 }
                 return ballot(sh_pending) != 0ull;
             });
 
+            STAMP(6); // shadow resolved
+            // keep the material / pattern loads of the lighting stage BELOW the shadow loop: hoisted
+            // above it they stay live through the loop and cost a wave per SIMD in occupancy
+            asm volatile("" ::: "memory");
             if constexpr (PROBE) if (first && in_range && P.hits) {
                 rtc_hit *H = reinterpret_cast<rtc_hit *>(P.hits) + ray_index;
                 H->hit_index = hit ? hidx : -1;
@@ -730,7 +812,7 @@ k_trace(const RenderParams P, const DevIsect *__restrict__ t_isect, const uint32
             if (tracing && !hit) { // background_color: BLACK shape.rs:652-653
                 have_val = true;
             } else if (hit) {
-                const V3 surface = lighting(P, S, m_obj, over, eyev, normal, sdir, shadowed);
+                const V3 surface = lighting(KP(P_arg), S, m_obj, over, eyev, normal, sdir, shadowed);
                 bool want_refl = false, want_refr = false;
                 V3 fr_o = mk(0, 0, 0), fr_d = mk(0, 0, 0);
                 if constexpr (REFL) want_refl = (rem != 0) && (m_kr > 0.); // reflected_color shape.rs:730
@@ -811,31 +893,41 @@ k_trace(const RenderParams P, const DevIsect *__restrict__ t_isect, const uint32
             }
         }
 
-        if (nsamples > 1u) acc = vadd(acc, result);
+        // Color::average_over (color.rs:128-139): reds = ((0 + c0) + c1) + ... ; the running sums
+        // live in the pixel's own canvas slot between samples, not in registers
+        if (in_range) {
+            const auto &Po = KP(P_arg); // output view
+            double *o = probe ? (Po.out + (size_t)ray_index * 3) : (Po.out + ((size_t)(py - Po.y0) * Po.W + px) * 3);
+            if (!traced) result = mk(0., 0., 0.); // Canvas::new BLACK canvas.rs:37-41
+            if (nsamples > 1u) {
+                V3 acc = (s == 0u) ? mk(0., 0., 0.) : mk(o[0], o[1], o[2]);
+                acc = vadd(acc, result);
+                if (s + 1u == nsamples) {
+                    const double l = (double)nsamples;
+                    acc = mk(acc.x / l, acc.y / l, acc.z / l);
+                }
+                result = acc;
+            }
+            o[0] = result.x;
+            o[1] = result.y;
+            o[2] = result.z;
+        }
     }
 
-    if (nsamples > 1u) { // Color::average_over color.rs:137-138
-        const double l = (double)nsamples;
-        result = mk(acc.x / l, acc.y / l, acc.z / l);
-    }
-
-    if (in_range) {
-        double *o = probe ? (P.out + (size_t)ray_index * 3) : (P.out + ((size_t)(py - P.y0) * P.W + px) * 3);
-        if (!traced) result = mk(0., 0., 0.); // Canvas::new BLACK canvas.rs:37-41
-        o[0] = result.x;
-        o[1] = result.y;
-        o[2] = result.z;
-    }
-
-    if (P.counters) {
+    STAMP(7); // shaded, stored
+    const auto &Pc = KP(P_arg);
+    if (Pc.counters) {
         const uint32_t npix = popc64(ballot(traced));
         if (lane == 0) {
-            unsigned long long *slot = P.counters + (size_t)((blockIdx.x * 4u + wave) % CNT_SLOTS) * CNT_N;
+            unsigned long long *slot = Pc.counters + (size_t)((blockIdx.x * 4u + wave) % CNT_SLOTS) * CNT_N;
             if (c_primary) atomicAdd(slot + CNT_PRIMARY, (unsigned long long)c_primary);
             if (c_shadow) atomicAdd(slot + CNT_SHADOW, (unsigned long long)c_shadow);
             if (c_reflect) atomicAdd(slot + CNT_REFLECT, (unsigned long long)c_reflect);
             if (c_refract) atomicAdd(slot + CNT_REFRACT, (unsigned long long)c_refract);
             if (npix) atomicAdd(slot + CNT_PIXELS, (unsigned long long)npix);
+#ifdef RTC_STAMPS
+            for (int i = 0; i < 7; ++i) atomicAdd(slot + CNT_STAMP0 + i, stamp_t[i + 1] - stamp_t[i]);
+#endif
         }
     }
 }

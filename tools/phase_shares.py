@@ -1,0 +1,37 @@
+"""Diagnostic: where does a wave of k_trace spend its cycles? Needs a -DRTC_STAMPS build
+(RTC_CXXFLAGS=-DRTC_STAMPS python raytracer-challenge_amd/build.py --force). Prints the share of
+each phase (s_memtime deltas summed over all waves). The stamped build serialises memory at every
+stamp, so only the SHARES are meaningful, never its run time."""
+import ctypes as C
+import importlib
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path[:0] = [str(ROOT)]
+from _bootstrap import package  # noqa: E402
+
+rtc = package()
+scenes = importlib.import_module(rtc.__name__ + ".scenes")
+import torch  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+w, cam = scenes.synthetic(n, 1920, 1080, with_plane=(n <= 1000))
+ctx = rtc.Context(0)
+dw = ctx.upload(w)
+buf = torch.zeros((1080, 1920, 3), dtype=torch.float64, device="cuda:0")
+torch.cuda.synchronize()
+for _ in range(3):
+    dw.render_rows(cam, 0, 1080, buf.data_ptr())
+ctx.reset_stats()
+dw.render_rows(cam, 0, 1080, buf.data_ptr())
+ctx.synchronize()
+out = (C.c_ulonglong * 16)()
+rtc.lib().rtc_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
+rtc.lib().rtc_debug_counters(ctx._h, out, 16)
+names = ["ray generation", "primary bundle", "primary cull + closest hit", "hit record + shadow ray", "shadow bundle",
+         "shadow cull + any-hit", "lighting + store"]
+tot = sum(out[8 + i] for i in range(7))
+print(f"objects {len(w)}  kernel_ms(stamped) {ctx.last_kernel_ms():.3f}  waves {out[0] // 64 if out[0] else 0}")
+for i, nm in enumerate(names):
+    print(f"  {nm:28s} {out[8 + i] / max(tot, 1) * 100:5.1f} %   {out[8 + i] / 32400:9.0f} ticks/wave")
