@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo is a rehearsal aid for boxes with fewer GPUs than ranks (tiles hop through host memory)")
     ap.add_argument("--no-overlap", action="store_true", help="wait for each gather before rendering the next frame")
+    ap.add_argument("--gather", default="u8", choices=["u8", "f64"],
+                    help="what rank 0 collects: the 8-bit frame (Color::scale, 3 B/pixel - what every file writer of the "
+                         "reference consumes) or the raw f64 canvas (24 B/pixel; xGMI-ingest bound at this frame size)")
     return ap.parse_args()
 
 
@@ -120,8 +123,12 @@ def main():
     # k+1 renders; a buffer is reused only after the gather that reads or fills it has completed
     nbuf = 1 if (world_size == 1 or args.no_overlap) else 2
     gdev = torch.device("cpu") if gloo else dev
+    # every step renders the f64 canvas tile (resident in HBM, Canvas::get_pixel semantics) AND its
+    # 8-bit quantisation; the exchange moves one of the two
+    gdtype = torch.uint8 if args.gather == "u8" else torch.float64
     tile_bufs = [torch.zeros((rows_max, W, 3), dtype=torch.float64, device=dev) for _ in range(nbuf)]
-    canvases = [torch.empty((world_size * rows_max, W, 3), dtype=torch.float64, device=gdev) for _ in range(nbuf)] \
+    tile8_bufs = [torch.zeros((rows_max, W, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    canvases = [torch.empty((world_size * rows_max, W, 3), dtype=gdtype, device=gdev) for _ in range(nbuf)] \
         if (rank == 0 and world_size > 1) else [None] * nbuf
     pending = [None] * nbuf
     state = {"k": 0}
@@ -132,14 +139,15 @@ def main():
         if pending[b] is not None:
             pending[b].wait()       # current stream waits for the gather that last used buffer b
             pending[b] = None
-        tile = tile_bufs[b]
+        tile, tile8 = tile_bufs[b], tile8_bufs[b]
         if ev:
             ev[0].record(stream)
-        dworld.render_rows(cam, y0, y1, tile.data_ptr(), rtc.MODE_RENDER_ASYNC)
+        dworld.render_rows(cam, y0, y1, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
         if ev:
             ev[1].record(stream)
         if world_size > 1:
-            src = tile.cpu() if gloo else tile
+            src = tile8 if args.gather == "u8" else tile
+            src = src.cpu() if gloo else src
             work = tiles.gather_tiles(src, canvases[b], world_size, rank, async_op=not args.no_overlap)
             if work is not None:
                 pending[b] = work

@@ -74,7 +74,7 @@ enum { /* render flags (bit set) */
     RTC_FLAG_NO_CULL   = 1u << 0, /* visit every object for every ray (plain brute force); the
                                      default culls objects with a conservative bound first and
                                      produces bit-identical results */
-    RTC_FLAG_QUANT_U8  = 1u << 1  /* reserved */
+    RTC_FLAG_RESERVED1 = 1u << 1
 };
 
 #define RTC_MAX_REFLECTIONS 5u /* Camera::MAX_REFLECTIONS camera.rs:31 */
@@ -225,6 +225,8 @@ void        rtc_free(void *p);
 rtc_status  rtc_canvas_write_ppm(const char *path, const double *rgb, uint32_t width, uint32_t height);
 /* The same encoder into memory: returns bytes needed (excluding NUL); writes at most cap. */
 size_t      rtc_canvas_format_ppm(const double *rgb, uint32_t width, uint32_t height, char *buf, size_t cap);
+/* Color::scale(c, 255) for n colour components (color.rs:100-114) on the host. */
+void        rtc_color_scale255(const double *components, size_t n, uint8_t *out);
 
 /* ==== [device] the hot path on one MI355X ========================================== */
 
@@ -246,9 +248,13 @@ void        rtc_world_destroy(rtc_world *w);
 
 /* Camera::render / render_async for canvas rows [y0, y1) into a DEVICE buffer of
  * (y1-y0)*hsize*3 doubles (row y0 first). Enqueues on the context stream and returns
- * without synchronising. Row-tiling hook for multi-GPU (each rank renders its rows). */
+ * without synchronising. Row-tiling hook for multi-GPU (each rank renders its rows).
+ * d_rgb8 (may be NULL): additionally receives the same rows quantised to 8 bits per channel,
+ * (y1-y0)*hsize*3 bytes, exactly as the reference's file writers quantise a Canvas
+ * (Color::scale(c, 255): truncating saturating cast, clamp; color.rs:100-114, canvas.rs:104). */
 rtc_status  rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,
-                            uint32_t mode, uint32_t y0, uint32_t y1, void *d_rgb, uint32_t flags);
+                            uint32_t mode, uint32_t y0, uint32_t y1, void *d_rgb, void *d_rgb8,
+                            uint32_t flags);
 /* Camera::render(&World) -> Canvas with host memory: renders all rows and copies the
  * canvas into `rgb` (vsize*hsize*3 doubles). Synchronous. `stats` may be NULL. */
 rtc_status  rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,

@@ -241,6 +241,14 @@ def format_ppm(rgb: np.ndarray) -> bytes:
     return buf.raw[:need]
 
 
+def color_scale255(rgb: np.ndarray) -> np.ndarray:
+    """Color::scale(c, 255) (color.rs:100-114) element-wise on the host."""
+    a = np.ascontiguousarray(rgb, dtype=np.float64)
+    out = np.empty(a.shape, dtype=np.uint8)
+    lib().rtc_color_scale255(a.ctypes.data_as(C.POINTER(C.c_double)), a.size, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
 def write_ppm(path, rgb: np.ndarray) -> None:
     a = np.ascontiguousarray(rgb, dtype=np.float64)
     _check(lib().rtc_canvas_write_ppm(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[1], a.shape[0]), "Canvas.write_to_file_simple")
@@ -343,9 +351,12 @@ class DeviceWorld:
                          "rays_refract": st.rays_refract, "pixels": st.pixels}
         return out
 
-    def render_rows(self, cam: RtcCamera, y0: int, y1: int, d_ptr: int, mode: int = MODE_RENDER_ASYNC, flags: int = 0) -> None:
-        """Enqueue rows [y0, y1) into the DEVICE buffer at address `d_ptr` (no synchronisation)."""
-        _check(lib().rtc_render_rows(self.ctx._h, self._h, C.byref(cam), mode, y0, y1, C.c_void_p(d_ptr), flags), "rtc_render_rows")
+    def render_rows(self, cam: RtcCamera, y0: int, y1: int, d_ptr: int, mode: int = MODE_RENDER_ASYNC, flags: int = 0,
+                    d_ptr8: int | None = None) -> None:
+        """Enqueue rows [y0, y1) into the DEVICE buffer at address `d_ptr` (no synchronisation);
+        `d_ptr8` optionally receives the rows quantised to 8 bits (Color::scale)."""
+        _check(lib().rtc_render_rows(self.ctx._h, self._h, C.byref(cam), mode, y0, y1, C.c_void_p(d_ptr),
+                                     C.c_void_p(d_ptr8 or None), flags), "rtc_render_rows")
 
     def color_at(self, rays: np.ndarray, remaining: int = 5, want_hits: bool = False, flags: int = 0):
         """World::color_at for an (n, 6) array of rays; returns rgb (n,3) [and the rtc_hit array]."""
@@ -359,5 +370,5 @@ class DeviceWorld:
 
 
 __all__ = ["lib", "RtcError", "Matrix", "material", "sphere", "plane", "cube", "light", "World", "camera", "ray_for_pixel",
-           "load_yaml", "format_ppm", "write_ppm", "Context", "DeviceWorld", "MODE_RENDER", "MODE_RENDER_ASYNC",
+           "load_yaml", "format_ppm", "write_ppm", "color_scale255", "Context", "DeviceWorld", "MODE_RENDER", "MODE_RENDER_ASYNC",
            "SPHERE", "PLANE", "CUBE", "RtcCamera", "RtcHit", "RtcLight", "RtcMaterial", "RtcShape", "RtcStats"]

@@ -81,13 +81,14 @@ PROTOTYPES = {
     "rtc_free": (None, [VP]),
     "rtc_canvas_write_ppm": (C.c_int32, [C.c_char_p, PD, U32, U32]),
     "rtc_canvas_format_ppm": (C.c_size_t, [PD, U32, U32, C.c_char_p, C.c_size_t]),
+    "rtc_color_scale255": (None, [PD, C.c_size_t, C.POINTER(C.c_uint8)]),
     "rtc_context_create": (C.c_int32, [C.c_int32, VP, C.POINTER(VP)]),
     "rtc_context_destroy": (None, [VP]),
     "rtc_context_synchronize": (C.c_int32, [VP]),
     "rtc_context_device_info": (C.c_int32, [VP, C.c_char_p, C.c_size_t, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "rtc_world_create": (C.c_int32, [VP, C.POINTER(RtcShape), U32, C.POINTER(RtcLight), C.POINTER(VP)]),
     "rtc_world_destroy": (None, [VP]),
-    "rtc_render_rows": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, U32, VP, U32]),
+    "rtc_render_rows": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, U32, VP, VP, U32]),
     "rtc_render": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, PD, C.POINTER(RtcStats)]),
     "rtc_stats_read": (C.c_int32, [VP, C.POINTER(RtcStats)]),
     "rtc_stats_reset": (C.c_int32, [VP]),

@@ -66,6 +66,11 @@ size_t rtc_canvas_format_ppm(const double *rgb, uint32_t width, uint32_t height,
     return s.size();
 }
 
+void rtc_color_scale255(const double *components, size_t n, uint8_t *out) {
+    if (!components || !out) return;
+    for (size_t i = 0; i < n; ++i) out[i] = static_cast<uint8_t>(scale255(components[i]));
+}
+
 rtc_status rtc_canvas_write_ppm(const char *path, const double *rgb, uint32_t width, uint32_t height) {
     if (!path || !rgb) return RTC_ERR_ARG;
     std::FILE *f = std::fopen(path, "wb");

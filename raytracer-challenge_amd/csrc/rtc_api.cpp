@@ -349,7 +349,7 @@ void rtc_world_destroy(rtc_world *w) {
 }
 
 rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode, uint32_t y0,
-                           uint32_t y1, void *d_rgb, uint32_t flags) {
+                           uint32_t y1, void *d_rgb, void *d_rgb8, uint32_t flags) {
     if (!ctx || !w || !cam || !d_rgb || w->ctx != ctx) return RTC_ERR_ARG;
     if (mode > RTC_MODE_RENDER_ASYNC || cam->hsize == 0 || cam->vsize == 0 || y0 > y1 || y1 > cam->vsize) return RTC_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -362,6 +362,7 @@ rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camer
     P.y1 = y1;
     P.mode = mode;
     P.out = static_cast<double *>(d_rgb);
+    P.out8 = static_cast<unsigned char *>(d_rgb8);
     P.counters = ctx->d_counters;
     P.rays = nullptr;
     P.remaining = RTC_MAX_REFLECTIONS; // render_pixel passes Camera::MAX_REFLECTIONS camera.rs:98
@@ -437,7 +438,7 @@ rtc_status rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *ca
     HIP_TRY(hipMalloc(&d, bytes));
     rtc_status st = RTC_OK;
     if (stats) st = rtc_stats_reset(ctx);
-    if (st == RTC_OK) st = rtc_render_rows(ctx, w, cam, mode, 0, cam->vsize, d, flags);
+    if (st == RTC_OK) st = rtc_render_rows(ctx, w, cam, mode, 0, cam->vsize, d, nullptr, flags);
     if (st == RTC_OK && hipMemcpyAsync(rgb, d, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
     if (st == RTC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
     if (st == RTC_OK && stats) st = rtc_stats_read(ctx, stats);

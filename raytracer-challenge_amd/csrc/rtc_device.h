@@ -60,6 +60,7 @@ struct RenderParams {
     double half_width, half_height, pixel_size;
     double vinv[12];
     double *out;                 // (y1-y0) x W x 3
+    unsigned char *out8;         // optional: the same rows quantised by Color::scale(c, 255)
     unsigned long long *counters; // CNT_N
     // probe mode (rtc_color_at): rays != nullptr
     const double *rays;

@@ -507,8 +507,13 @@ DEVI V3 lighting(const PP &P, const DevShade *S, const double *m_obj, V3 point, 
         const V3 reflectv = vreflect(vneg(lightv), normal);
         const double rde = vdot(reflectv, eyev);
         if (!(rde <= 0.)) {
-            const double factor = pow(rde, S->shininess);
-            specular = vmul(I, S->specular * factor);
+            // factor = rde.powf(shininess) (material.rs:355). When specular == 0 and the power is
+            // certainly finite and positive (0 < rde <= 1, 0 <= shininess < inf), specular*factor is
+            // exactly specular (a signed zero) whatever the power is: skip the ~200-instruction pow.
+            const double ks = S->specular, sh = S->shininess;
+            const bool trivial = (ks == 0.0) && (rde <= 1.0) && (sh >= 0.0) && (sh < __builtin_inf());
+            const double factor = trivial ? 1.0 : pow(rde, sh);
+            specular = vmul(I, ks * factor);
         }
     }
     return vadd(vadd(ambient, diffuse), specular);
@@ -553,6 +558,15 @@ struct Frame {
     uint8_t schlick;
     uint8_t has_refr;
 };
+
+// Color::scale(component, 255) color.rs:100-114: `(c * 255.0) as i32` (truncating, saturating,
+// NaN -> 0) then clamp to [0, 255].
+DEVI unsigned char scale255(double c) {
+    const double v = c * 255.0;
+    if (!(v >= 0.0)) return 0;   // negative (truncates to <= 0, clamps to 0) or NaN
+    if (v >= 255.0) return 255;  // saturates / clamps
+    return (unsigned char)(int)v; // v_cvt_i32_f64 truncates toward zero
+}
 
 // shade_hit's final combination shape.rs:692-699
 DEVI V3 combine(V3 surface, V3 reflected, V3 refracted, bool schlick, double R) {
@@ -697,13 +711,15 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             if (hit) {
                 point = vadd(ro, vmul(rd, best)); // Ray::position vec.rs:207-209
                 eyev = vneg(rd);
-                // Shape::normal_at shape.rs:34-40
-                const V3 lp = xpoint(m_obj, point);
+                // Shape::normal_at shape.rs:34-40 (a plane's local normal ignores the local point)
                 V3 ln;
                 const uint32_t kind = S->kind;
-                if (kind == RTC_SPHERE) ln = mk(lp.x - 0., lp.y - 0., lp.z - 0.);
-                else if (kind == RTC_PLANE) ln = mk(0., 1., 0.);
-                else { // Cube::normal_at_local shape.rs:601-610
+                if (kind == RTC_PLANE) ln = mk(0., 1., 0.);
+                else if (kind == RTC_SPHERE) {
+                    const V3 lp = xpoint(m_obj, point);
+                    ln = mk(lp.x - 0., lp.y - 0., lp.z - 0.);
+                } else { // Cube::normal_at_local shape.rs:601-610
+                    const V3 lp = xpoint(m_obj, point);
                     const double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
                     const double maxc = fmax(ax, fmax(ay, az));
                     if (maxc == ax) ln = mk(lp.x, 0., 0.);
@@ -911,6 +927,14 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             o[0] = result.x;
             o[1] = result.y;
             o[2] = result.z;
+            if constexpr (!PROBE) {
+                if (Po.out8 && s + 1u == nsamples) {
+                    unsigned char *q = Po.out8 + ((size_t)(py - Po.y0) * Po.W + px) * 3;
+                    q[0] = scale255(result.x);
+                    q[1] = scale255(result.y);
+                    q[2] = scale255(result.z);
+                }
+            }
         }
     }
 

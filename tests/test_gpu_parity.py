@@ -279,6 +279,29 @@ def test_row_tiles_compose_exactly(rtc, gpu, scenes):
     assert np.array_equal(buf.cpu().numpy(), full)
 
 
+def test_quantised_rows_match_color_scale(rtc, gpu, O, scenes):
+    """rtc_render_rows' optional 8-bit output == Color::scale(c, 255) (color.rs:100-114) of the f64
+    canvas the same launch wrote (exact), and == the oracle's quantisation of its own canvas except
+    where pow's last-ulp difference straddles an integer boundary (none expected)."""
+    import torch
+    for (w, cam) in (scenes.synthetic(40, 160, 90), scenes.test8(96, 72), scenes.synthetic(12, 64, 48, samples=4)):
+        dw = gpu.upload(w)
+        H, W = cam.vsize, cam.hsize
+        f = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda:0")
+        q = torch.full((H, W, 3), 7, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        dw.render_rows(cam, 0, H, f.data_ptr(), d_ptr8=q.data_ptr())
+        gpu.synchronize()
+        fh, qh = f.cpu().numpy(), q.cpu().numpy()
+        assert np.array_equal(qh, rtc.color_scale255(fh))
+        want = O.render(w.array(), len(w), w.light, cam, mode=1, nthreads=8)
+        oq = np.array([[[O.lib().orc_color_scale(float(c), 255) for c in px] for px in row] for row in want], dtype=np.uint8)
+        assert (qh != oq).sum() <= 2
+        dw.close()
+    edge = np.array([float("nan"), -1e300, -0.0, 0.0, 0.999999, 1.0, 1e300, 0.5, 254.999 / 255, 1 / 255, float("inf"), -float("inf")])
+    assert list(rtc.color_scale255(edge)) == [0, 0, 0, 0, 254, 255, 255, 127, 254, 1, 255, 0]
+
+
 def test_empty_world_and_error_paths(rtc, gpu):
     """Empty worlds render black; a material with neither colour nor pattern is rejected
     (material.rs:328-331 panics in the reference); singular transforms are rejected

@@ -157,6 +157,15 @@ def test_ppm_writer_matches_oracle_and_format(rtc, O, tmp_path):
     assert rtc.format_ppm(gold) == (ROOT / "tests" / "golden" / "jamis_100x50.ppm").read_bytes()
 
 
+def test_color_scale255_matches_oracle(rtc, O):
+    """color.rs:100-114 on the host: product vs oracle on random and edge values."""
+    rng = np.random.default_rng(8)
+    v = np.concatenate([rng.uniform(-0.5, 1.5, 5000), np.arange(0, 256) / 255.0, [float("nan"), float("inf"), -float("inf"), -0.0, 1e300, -1e300]])
+    got = rtc.color_scale255(v)
+    want = np.array([O.lib().orc_color_scale(float(x), 255) for x in v], dtype=np.uint8)
+    assert np.array_equal(got, want)
+
+
 def test_yaml_loader_builds_the_reference_constructors_world(rtc, O):
     """The loader's output equals a World built by hand with the reference's constructor order
     (SURVEY.md App. C): floor = Plane(identity.rotation_y(0.31415)), walls, spheres ..."""
