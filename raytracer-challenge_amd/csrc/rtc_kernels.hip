@@ -27,11 +27,12 @@
 
 #define RTC_BLOCK 256
 #define RTC_MAX_STACK 8
-// 2nd argument of __launch_bounds__ = minimum waves per SIMD (caps VGPRs: 3 -> 168, 2 -> 256).
-// Measured on the north-star scene (culled flat kernel): 2 -> 0.171 ms, 3 -> 0.139 ms, 4 -> 0.159 ms
-// (4 spills). Kernels that carry the reflection/refraction frame stack keep 2.
+// 2nd argument of __launch_bounds__ = minimum waves per SIMD (caps VGPRs: 4 -> 128, 3 -> 168,
+// 2 -> 256). Measured on the north-star scene (culled flat kernel, 143 VGPRs uncapped):
+// 3 -> 0.139 ms, 4 -> 0.124 ms (40 B/lane of scratch), 5 -> 0.145 ms. Kernels that carry the
+// reflection/refraction frame stack keep 2.
 #ifndef RTC_WAVES_PER_SIMD
-#define RTC_WAVES_PER_SIMD 3
+#define RTC_WAVES_PER_SIMD 4
 #endif
 #ifndef RTC_WAVES_PER_SIMD_STACK
 #define RTC_WAVES_PER_SIMD_STACK 2
@@ -494,27 +495,41 @@ DEVI V3 pattern_color(const DevShade *S, const double *m_obj, V3 world_point) {
 template <class PP>
 DEVI V3 lighting(const PP &P, const DevShade *S, const double *m_obj, V3 point, V3 eyev, V3 normal,
                  V3 lightv, bool in_shadow) {
+    // The reference's statement order is effective_color, lightv, ambient, [shadow?] light_dot_normal,
+    // diffuse, reflectv, reflect_dot_eye, factor, specular. The values do not depend on that order
+    // (no shared rounding), so the geometric scalars and the one expensive call (pow) are done FIRST,
+    // while little else is live, and the colour arithmetic afterwards.
+    double ldn = 0., kspec = 0.;
+    bool lit = false, spec = false;
+    if (!in_shadow) {
+        ldn = vdot(lightv, normal);
+        if (!(ldn < 0.)) {
+            lit = true;
+            const V3 reflectv = vreflect(vneg(lightv), normal);
+            const double rde = vdot(reflectv, eyev);
+            if (!(rde <= 0.)) {
+                // factor = rde.powf(shininess) (material.rs:355). When specular == 0 and the power is
+                // certainly finite and positive (0 < rde <= 1, 0 <= shininess < inf), specular*factor is
+                // exactly specular (a signed zero) whatever the power is: skip the ~200-instruction pow.
+                const double ks = S->specular, sh = S->shininess;
+                const bool trivial = (ks == 0.0) && (rde <= 1.0) && (sh >= 0.0) && (sh < __builtin_inf());
+                const double factor = trivial ? 1.0 : pow(rde, sh);
+                kspec = ks * factor;
+                spec = true;
+            }
+        }
+    }
+    asm volatile("" ::: "memory"); // the material colour / pattern loads start here, not above the pow
     const V3 I = mk(P.light_int[0], P.light_int[1], P.light_int[2]);
     const V3 base = (S->pattern_kind != RTC_PATTERN_NONE) ? pattern_color(S, m_obj, point)
                                                           : mk(S->color[0], S->color[1], S->color[2]);
     const V3 eff = vmulv(base, I);
     const V3 ambient = vmul(eff, S->ambient);
     if (in_shadow) return ambient;
-    const double ldn = vdot(lightv, normal);
     V3 diffuse = mk(0., 0., 0.), specular = mk(0., 0., 0.);
-    if (!(ldn < 0.)) {
+    if (lit) {
         diffuse = vmul(eff, S->diffuse * ldn);
-        const V3 reflectv = vreflect(vneg(lightv), normal);
-        const double rde = vdot(reflectv, eyev);
-        if (!(rde <= 0.)) {
-            // factor = rde.powf(shininess) (material.rs:355). When specular == 0 and the power is
-            // certainly finite and positive (0 < rde <= 1, 0 <= shininess < inf), specular*factor is
-            // exactly specular (a signed zero) whatever the power is: skip the ~200-instruction pow.
-            const double ks = S->specular, sh = S->shininess;
-            const bool trivial = (ks == 0.0) && (rde <= 1.0) && (sh >= 0.0) && (sh < __builtin_inf());
-            const double factor = trivial ? 1.0 : pow(rde, sh);
-            specular = vmul(I, ks * factor);
-        }
+        if (spec) specular = vmul(I, kspec);
     }
     return vadd(vadd(ambient, diffuse), specular);
 }
@@ -636,7 +651,8 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
         bool shared_origin;
         const auto &Pr = KP(P_arg); // ray-generation view: camera block
         // ray origin of every primary ray: transform_point(view_inv, (0,0,0)) camera.rs:72
-        const V3 cam_origin = xpoint(Pr.vinv, mk(0., 0., 0.));
+        V3 cam_origin = xpoint(Pr.vinv, mk(0., 0., 0.));
+        cam_origin = mk(uniform_f64(cam_origin.x), uniform_f64(cam_origin.y), uniform_f64(cam_origin.z)); // same in every lane
         if (probe) {
             const double *rp = P.rays + (size_t)(in_range ? ray_index : 0u) * 6;
             ro = mk(rp[0], rp[1], rp[2]);
@@ -662,11 +678,17 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
         int sp = 0;
         c_primary += popc64(ballot(tracing));
 
-        for (;;) {
-            bool any_tracing;
-            if constexpr (SRC == SRC_LDSN) any_tracing = __syncthreads_or(tracing ? 1 : 0) != 0;
-            else any_tracing = ballot(tracing) != 0ull;
-            if (!any_tracing) break;
+        // Worlds without reflective / transparent materials (REFL == false) need exactly one pass per
+        // primary ray; otherwise loop until every lane's frame stack has unwound.
+        for (bool pass_again = true; pass_again;) {
+            if constexpr (REFL) {
+                bool any_tracing;
+                if constexpr (SRC == SRC_LDSN) any_tracing = __syncthreads_or(tracing ? 1 : 0) != 0;
+                else any_tracing = ballot(tracing) != 0ull;
+                if (!any_tracing) break;
+            } else {
+                pass_again = false;
+            }
 
             STAMP(1); // ray generated
             // ---- World::intersect + get_hit (shape.rs:677-683, 220-232), streaming form ----
@@ -898,14 +920,18 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                         }
                     }
                 }
-                if (!relaunched) {
-                    result = val;
-                    tracing = false;
+                if constexpr (REFL) {
+                    if (!relaunched) {
+                        result = val;
+                        tracing = false;
+                    }
                 }
             }
             if constexpr (REFL) {
                 c_reflect += popc64(ballot(l_refl));
                 c_refract += popc64(ballot(l_refr));
+            } else {
+                result = val; // BLACK for lanes that traced nothing or missed (val starts at 0)
             }
         }
 
