@@ -5,6 +5,7 @@
 // point returns RTC_ERR_DEVICE.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -21,7 +22,7 @@ extern "C" hipError_t rtc_launch_prep(const DevIsect *isect, DevPrim *prim, uint
 extern "C" hipError_t rtc_launch_arith(uint32_t op, const double *a, const double *b, uint32_t n, double *out,
                                        hipStream_t stream);
 
-enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2, SRC_CULL = 3 };
+enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2, SRC_CULL = 3, SRC_CULL2 = 4 };
 
 struct rtc_context {
     int device = -1;
@@ -42,6 +43,12 @@ struct rtc_world {
     DevShade *d_shade = nullptr;
     DevPrim *d_prim = nullptr;
     DevBound *d_bound = nullptr;
+    DevIsect *d_isect_s = nullptr; // Morton-sorted copies for the two-level cull
+    uint32_t *d_kind_s = nullptr;
+    DevBound *d_bound_s = nullptr;
+    uint32_t *d_orig_s = nullptr;
+    DevBound *d_gbound = nullptr;
+    uint32_t ngroups = 0;
     rtc_light light{};
     bool any_refl = false, any_refr = false;
 };
@@ -63,7 +70,8 @@ void choose_source(const rtc_context *ctx, uint32_t n, uint32_t flags, int *src,
     const uint32_t per_obj = 96 + 32 + 4;
     int s;
     if (ctx->force_src >= 0) s = ctx->force_src;
-    else if (!(flags & RTC_FLAG_NO_CULL)) s = SRC_CULL; // default: per-wave conservative cull
+    else if (!(flags & RTC_FLAG_NO_CULL)) s = (n > 256) ? SRC_CULL2 : SRC_CULL; // default: per-wave conservative cull,
+                                                                              // two-level above 4 groups of 64
     else if (n <= 128) s = SRC_SMEM;
     else if (n <= 448) s = SRC_LDS1;
     else s = SRC_LDSN;
@@ -73,11 +81,34 @@ void choose_source(const rtc_context *ctx, uint32_t n, uint32_t flags, int *src,
         else cap = n ? n : 1;
     }
     if (s == SRC_LDSN) cap = ctx->tile_cap;
-    if (s == SRC_SMEM || s == SRC_CULL) cap = 0;
+    if (s == SRC_SMEM || s == SRC_CULL || s == SRC_CULL2) cap = 0;
     *src = s;
     *tile_cap = cap;
     // kinds sit behind cap*16 doubles; round the block up to 16 bytes
     *lds_bytes = cap ? (((size_t)cap * per_obj + 15) & ~(size_t)15) : 0;
+}
+
+// 63-bit Morton key of a point inside the box [lo, hi]^3 (21 bits per axis).
+uint64_t spread21(uint64_t v) {
+    v &= 0x1fffffULL;
+    v = (v | (v << 32)) & 0x1f00000000ffffULL;
+    v = (v | (v << 16)) & 0x1f0000ff0000ffULL;
+    v = (v | (v << 8)) & 0x100f00f00f00f00fULL;
+    v = (v | (v << 4)) & 0x10c30c30c30c30c3ULL;
+    v = (v | (v << 2)) & 0x1249249249249249ULL;
+    return v;
+}
+uint64_t morton_key(const DevBound &b, const double lo[3], const double hi[3]) {
+    uint64_t k = 0;
+    const double c[3] = {b.cx, b.cy, b.cz};
+    for (int a = 0; a < 3; ++a) {
+        const double ext = hi[a] - lo[a];
+        double u = ext > 0. ? (c[a] - lo[a]) / ext : 0.;
+        if (!(u >= 0.)) u = 0.;
+        if (u > 1.) u = 1.;
+        k |= spread21((uint64_t)(u * 2097151.0)) << a;
+    }
+    return k;
 }
 
 // World-space bounding sphere of a shape, derived from the stored inverse transform only (that is
@@ -187,6 +218,12 @@ void fill_world(RenderParams &P, const rtc_world *w) {
     P.shade = w->d_shade;
     P.prim = w->d_prim;
     P.bound = w->d_bound;
+    P.isect_s = w->d_isect_s;
+    P.kind_s = w->d_kind_s;
+    P.bound_s = w->d_bound_s;
+    P.orig_s = w->d_orig_s;
+    P.gbound = w->d_gbound;
+    P.ngroups = w->ngroups;
     P.n = w->n;
     for (int i = 0; i < 3; ++i) {
         P.light_pos[i] = w->light.position[i];
@@ -220,7 +257,7 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
     }
     if (const char *e = std::getenv("RTC_SRC")) {
         const int v = std::atoi(e);
-        if (v >= 0 && v <= 3) ctx->force_src = v;
+        if (v >= 0 && v <= 4) ctx->force_src = v;
     }
     if (const char *e = std::getenv("RTC_TILE_CAP")) {
         const int v = std::atoi(e);
@@ -308,9 +345,61 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
         if (m.transparency != 0.0) any_refr = true; // refracted_color shape.rs:752
         bound[i] = bound_of(s);
     }
+    // ---- two-level cull tables: unbounded objects first, the rest in Morton order of their centres;
+    // groups of 64 consecutive entries get a sphere around their members (inf if any is unbounded)
+    std::vector<uint32_t> order(na, 0);
+    for (uint32_t i = 0; i < n; ++i) order[i] = i;
+    {
+        double lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (uint32_t i = 0; i < n; ++i)
+            if (std::isfinite(bound[i].r)) {
+                const double c[3] = {bound[i].cx, bound[i].cy, bound[i].cz};
+                for (int a = 0; a < 3; ++a) { lo[a] = std::fmin(lo[a], c[a]); hi[a] = std::fmax(hi[a], c[a]); }
+            }
+        std::vector<uint64_t> key(na, 0);
+        for (uint32_t i = 0; i < n; ++i) key[i] = std::isfinite(bound[i].r) ? (1ULL << 63) | morton_key(bound[i], lo, hi) : 0ULL;
+        std::stable_sort(order.begin(), order.begin() + n, [&](uint32_t a, uint32_t b) { return key[a] < key[b]; });
+    }
+    const uint32_t ngroups = (n + 63u) / 64u;
+    std::vector<DevIsect> isect_s(na);
+    std::vector<uint32_t> kind_s(na, 0), orig_s(na, 0);
+    std::vector<DevBound> bound_s(na), gbound(ngroups ? ngroups : 1);
+    std::memset(isect_s.data(), 0, sizeof(DevIsect) * na);
+    for (uint32_t i = 0; i < na; ++i) bound_s[i] = DevBound{0., 0., 0., INFINITY};
+    for (uint32_t i = 0; i < n; ++i) {
+        isect_s[i] = isect[order[i]];
+        kind_s[i] = kind[order[i]];
+        bound_s[i] = bound[order[i]];
+        orig_s[i] = order[i];
+    }
+    gbound[0] = DevBound{0., 0., 0., INFINITY};
+    for (uint32_t g = 0; g < ngroups; ++g) {
+        const uint32_t a = g * 64u, b = (a + 64u < n) ? a + 64u : n;
+        DevBound gb{0., 0., 0., INFINITY};
+        bool finite = true;
+        double cx = 0., cy = 0., cz = 0.;
+        for (uint32_t i = a; i < b; ++i) {
+            if (!std::isfinite(bound_s[i].r)) { finite = false; break; }
+            cx += bound_s[i].cx; cy += bound_s[i].cy; cz += bound_s[i].cz;
+        }
+        if (finite && b > a) {
+            const double cnt = (double)(b - a);
+            cx /= cnt; cy /= cnt; cz /= cnt;
+            double r = 0.;
+            for (uint32_t i = a; i < b; ++i) {
+                const double dx = bound_s[i].cx - cx, dy = bound_s[i].cy - cy, dz = bound_s[i].cz - cz;
+                r = std::fmax(r, std::sqrt(dx * dx + dy * dy + dz * dz) + bound_s[i].r);
+            }
+            r = r * (1. + 1e-9) + 1e-12;
+            if (std::isfinite(r) && std::isfinite(cx) && std::isfinite(cy) && std::isfinite(cz)) gb = DevBound{cx, cy, cz, r};
+        }
+        gbound[g] = gb;
+    }
+
     rtc_world *w = new (std::nothrow) rtc_world;
     if (!w) return RTC_ERR_NOMEM;
     w->ctx = ctx;
+    w->ngroups = ngroups;
     w->device = ctx->device;
     w->n = n;
     w->light = *light;
@@ -320,11 +409,21 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
               hipMalloc(&w->d_kind, sizeof(uint32_t) * na) == hipSuccess &&
               hipMalloc(&w->d_shade, sizeof(DevShade) * na) == hipSuccess &&
               hipMalloc(&w->d_prim, sizeof(DevPrim) * na) == hipSuccess &&
-              hipMalloc(&w->d_bound, sizeof(DevBound) * na) == hipSuccess;
+              hipMalloc(&w->d_bound, sizeof(DevBound) * na) == hipSuccess &&
+              hipMalloc(&w->d_isect_s, sizeof(DevIsect) * na) == hipSuccess &&
+              hipMalloc(&w->d_kind_s, sizeof(uint32_t) * na) == hipSuccess &&
+              hipMalloc(&w->d_bound_s, sizeof(DevBound) * na) == hipSuccess &&
+              hipMalloc(&w->d_orig_s, sizeof(uint32_t) * na) == hipSuccess &&
+              hipMalloc(&w->d_gbound, sizeof(DevBound) * gbound.size()) == hipSuccess;
     ok = ok && hipMemcpy(w->d_isect, isect.data(), sizeof(DevIsect) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_kind, kind.data(), sizeof(uint32_t) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_shade, shade.data(), sizeof(DevShade) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_bound, bound.data(), sizeof(DevBound) * na, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(w->d_isect_s, isect_s.data(), sizeof(DevIsect) * na, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(w->d_kind_s, kind_s.data(), sizeof(uint32_t) * na, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(w->d_bound_s, bound_s.data(), sizeof(DevBound) * na, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(w->d_orig_s, orig_s.data(), sizeof(uint32_t) * na, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(w->d_gbound, gbound.data(), sizeof(DevBound) * gbound.size(), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(w->d_prim, 0, sizeof(DevPrim) * na) == hipSuccess;
     if (!ok) {
         rtc_world_destroy(w);
@@ -345,6 +444,11 @@ void rtc_world_destroy(rtc_world *w) {
     if (w->d_shade) (void)hipFree(w->d_shade);
     if (w->d_prim) (void)hipFree(w->d_prim);
     if (w->d_bound) (void)hipFree(w->d_bound);
+    if (w->d_isect_s) (void)hipFree(w->d_isect_s);
+    if (w->d_kind_s) (void)hipFree(w->d_kind_s);
+    if (w->d_bound_s) (void)hipFree(w->d_bound_s);
+    if (w->d_orig_s) (void)hipFree(w->d_orig_s);
+    if (w->d_gbound) (void)hipFree(w->d_gbound);
     delete w;
 }
 
@@ -372,7 +476,7 @@ rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camer
     size_t lds_bytes;
     choose_source(ctx, w->n, flags, &src, &P.tile_cap, &lds_bytes);
     P.flags = flags;
-    if (src != SRC_CULL) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.vinv, ctx->stream));
+    if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.vinv, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y, lds_bytes, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));

@@ -9,6 +9,8 @@
 //   bound[n]  32 B  f64 world-space bounding sphere (centre, radius) for the conservative cull.
 //   shade[n] 320 B  what shade_hit needs for the ONE object a ray hit: inverse-transpose 3x3,
 //                   material scalars, pattern; gathered per lane after the hit is known.
+//   isect_s/kind_s/bound_s/orig_s[n], gbound[ceil(n/64)]: the same records in Morton order of the
+//                   bound centres with one bounding sphere per group of 64 — the two-level cull.
 //   prim[n]   32 B  per-render scratch: the camera origin in object space and `c` of the sphere
 //                   quadratic — identical for every primary ray, so computed once per object
 //                   (with the reference's arithmetic) instead of once per pixel x object.
@@ -52,6 +54,13 @@ struct RenderParams {
     const DevShade *shade;
     const DevPrim *prim;
     const DevBound *bound;
+    // cull tables: objects in Morton order of their bound centres (unbounded ones first), grouped by 64
+    const DevIsect *isect_s;   // [n] records in sorted order
+    const uint32_t *kind_s;    // [n]
+    const DevBound *bound_s;   // [n]
+    const uint32_t *orig_s;    // [n] sorted position -> insertion index (World.shapes order)
+    const DevBound *gbound;    // [ngroups] sphere around each group of 64 sorted objects
+    uint32_t ngroups;
     uint32_t n;
     uint32_t tile_cap; // objects per LDS tile (LDS variants)
     double light_pos[3], light_int[3];

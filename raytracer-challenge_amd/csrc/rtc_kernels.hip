@@ -38,7 +38,8 @@
 #define RTC_WAVES_PER_SIMD_STACK 2
 #endif
 
-enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2, SRC_CULL = 3 };
+enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2, SRC_CULL = 3, SRC_CULL2 = 4 };
+#define IS_CULL(S) ((S) == SRC_CULL || (S) == SRC_CULL2)
 
 struct V3 {
     double x, y, z;
@@ -143,6 +144,13 @@ template <bool HAVE_C> DEVI int shape_entries(uint32_t kind, V3 o, V3 d, double 
     }
 }
 
+// Does entry (t, object j) come before the current best entry (best, hidx) in the reference's
+// merged sorted list? Smaller t first; at equal t the shape inserted first (lower index); an
+// object's own second root never precedes its first (t1 <= t2 and j == hidx fails the test).
+// Visiting objects in insertion order makes the index comparison redundant but harmless; the
+// culled path visits them in Morton order and needs it.
+DEVI bool closer(double t, int j, double best, int hidx) { return t < best || (t == best && j < hidx); }
+
 // Closest-hit update for one object: Intersections::get_hit (shape.rs:220-232) over the merged
 // sorted list == smallest t >= 0.0, ties to the entry inserted first (lower object index, then
 // first root). For a sphere t1 <= t2, so the second root is only needed when the first is not
@@ -167,17 +175,17 @@ DEVI void closest_update(uint32_t kind, V3 o, V3 d, double c_pre, int j, double 
             const double den = 2. * a;
             const double t1 = (-b - sq) / den;
             if (t1 >= 0.0) {
-                if (t1 < best) { best = t1; hidx = j; hroot = 0; }
+                if (closer(t1, j, best, hidx)) { best = t1; hidx = j; hroot = 0; }
             } else {
                 const double t2 = (-b + sq) / den;
-                if (t2 >= 0.0 && t2 < best) { best = t2; hidx = j; hroot = 1; }
+                if (t2 >= 0.0 && closer(t2, j, best, hidx)) { best = t2; hidx = j; hroot = 1; }
             }
         }
     } else {
         double t0 = 0., t1 = 0.;
         const int cnt = shape_entries<false>(kind, o, d, 0., t0, t1);
-        if (cnt >= 1 && t0 >= 0.0 && t0 < best) { best = t0; hidx = j; hroot = 0; }
-        if (cnt == 2 && t1 >= 0.0 && t1 < best) { best = t1; hidx = j; hroot = 1; }
+        if (cnt >= 1 && t0 >= 0.0 && closer(t0, j, best, hidx)) { best = t0; hidx = j; hroot = 0; }
+        if (cnt == 2 && t1 >= 0.0 && closer(t1, j, best, hidx)) { best = t1; hidx = j; hroot = 1; }
     }
 }
 
@@ -208,7 +216,7 @@ template <class P> DEVI void closest_world(uint32_t kind, P m, V3 ro, V3 rd, int
         const double oy = xpoint_y(m, ro), dy = xvector_y(m, rd);
         if (!(fabs(dy) < RTC_EPSILON)) {
             const double t = -oy / dy;
-            if (t >= 0.0 && t < best) { best = t; hidx = j; hroot = 0; }
+            if (t >= 0.0 && closer(t, j, best, hidx)) { best = t; hidx = j; hroot = 0; }
         }
     } else {
         closest_update<false>(kind, xpoint(m, ro), xvector(m, rd), 0., j, best, hidx, hroot);
@@ -396,6 +404,12 @@ struct Tables {
     const DevShade *__restrict__ shade;
     const DevPrim *__restrict__ prim;
     const DevBound *__restrict__ bound;
+    // two-level cull tables (Morton order, groups of 64)
+    const DevIsect *__restrict__ isect_s;
+    const uint32_t *__restrict__ kind_s;
+    const DevBound *__restrict__ bound_s;
+    const uint32_t *__restrict__ orig_s;
+    const DevBound *__restrict__ gbound;
 };
 
 struct LdsView {
@@ -423,9 +437,9 @@ DEVI void stage_tile(const Tables &T, const LdsView &L, uint32_t base, uint32_t 
 template <int SRC, class PP, class F>
 DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool lane_needs, const Bundle &B, F &&f) {
     if constexpr (SRC == SRC_CULL) {
-        // 64 objects at a time: each lane tests one object's bound against the wave's bundle; the
-        // ballot mask is walked in ascending object order (= insertion order, which the closest-hit
-        // tie-break relies on); survivors' records come through the scalar cache (uniform index).
+        // One-level cull (small worlds): 64 objects at a time, each lane tests one object's sphere
+        // against the wave's bundle; the ballot mask is walked in ascending (= insertion) order and
+        // the survivors get the exact test, their records fetched by uniform index (scalar cache).
         if (ballot(lane_needs) == 0ull) return;
         const uint32_t lane = threadIdx.x & 63u;
         for (uint32_t base = 0; base < P.n; base += 64u) {
@@ -437,7 +451,34 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
                 const uint32_t jj = base + (uint32_t)__builtin_ctzll(mask);
                 mask &= mask - 1ull;
                 const DevIsect *rec = T.isect + jj;
-                if (!f((int)jj, rec->m, T.kind[jj], reinterpret_cast<const double *>(T.prim + jj))) return;
+                if (!f((int)jj, rec->m, T.kind[jj], (const double *)nullptr)) return;
+            }
+        }
+    } else if constexpr (SRC == SRC_CULL2) {
+        // Two-level cull (large worlds) over the Morton-sorted tables. Level 1: 64 GROUPS at a time,
+        // one group sphere per lane against the wave's bundle. Level 2, per surviving group: its 64
+        // objects, one object sphere per lane. Objects are not visited in insertion order here, so
+        // the callback receives the insertion index and the tie-break compares it (closer()).
+        if (ballot(lane_needs) == 0ull) return;
+        const uint32_t lane = threadIdx.x & 63u;
+        for (uint32_t gbase = 0; gbase < P.ngroups; gbase += 64u) {
+            const uint32_t g = gbase + lane;
+            bool gc = false;
+            if (g < P.ngroups) gc = bundle_touches(B, T.gbound[g]);
+            unsigned long long gmask = ballot(gc);
+            while (gmask) {
+                const uint32_t base = (gbase + (uint32_t)__builtin_ctzll(gmask)) * 64u;
+                gmask &= gmask - 1ull;
+                const uint32_t j = base + lane;
+                bool cand = false;
+                if (j < P.n) cand = bundle_touches(B, T.bound_s[j]);
+                unsigned long long mask = ballot(cand);
+                while (mask) {
+                    const uint32_t jj = base + (uint32_t)__builtin_ctzll(mask);
+                    mask &= mask - 1ull;
+                    const DevIsect *rec = T.isect_s + jj;
+                    if (!f((int)T.orig_s[jj], rec->m, T.kind_s[jj], (const double *)nullptr)) return;
+                }
             }
         }
     } else if constexpr (SRC == SRC_SMEM) {
@@ -595,12 +636,15 @@ DEVI V3 combine(V3 surface, V3 reflected, V3 refracted, bool schlick, double R) 
 template <int SRC, bool REFL, bool REFR, bool PROBE>
 __global__ void __launch_bounds__(RTC_BLOCK, (REFL ? RTC_WAVES_PER_SIMD_STACK : RTC_WAVES_PER_SIMD))
 k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const uint32_t *__restrict__ t_kind,
-        const DevShade *__restrict__ t_shade, const DevPrim *__restrict__ t_prim, const DevBound *__restrict__ t_bound) {
+        const DevShade *__restrict__ t_shade, const DevPrim *__restrict__ t_prim, const DevBound *__restrict__ t_bound,
+        const DevIsect *__restrict__ t_isect_s, const uint32_t *__restrict__ t_kind_s, const DevBound *__restrict__ t_bound_s,
+        const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound) {
     extern __shared__ double lds_raw[];
     const auto &P = KP(P_arg); // set-up view: grid, sizes, mode
     const LdsView L = lds_view(lds_raw, P.tile_cap);
     Tables T;
     T.isect = t_isect; T.kind = t_kind; T.shade = t_shade; T.prim = t_prim; T.bound = t_bound;
+    T.isect_s = t_isect_s; T.kind_s = t_kind_s; T.bound_s = t_bound_s; T.orig_s = t_orig_s; T.gbound = t_gbound;
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -696,14 +740,14 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             int hidx = -1, hroot = 0;
             Bundle B;
             B.off = true;
-            if constexpr (SRC == SRC_CULL) {
+            if constexpr (IS_CULL(SRC)) {
                 if (ballot(tracing) != 0ull) {
                     if (shared_origin && first) B = make_bundle<true, false>(tracing, cam_origin, ro, rd, 0.);
                     else B = make_bundle<false, false>(tracing, cam_origin, ro, rd, 0.);
                 }
             }
             STAMP(2); // primary bundle built
-            if (SRC != SRC_CULL && shared_origin && first) {
+            if (!IS_CULL(SRC) && shared_origin && first) {
                 for_each_object<SRC>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
                     if (tracing) {
                         const V3 o = mk(pr[0], pr[1], pr[2]);
@@ -811,7 +855,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             c_shadow += popc64(ballot(hit));
             Bundle Bs;
             Bs.off = true;
-            if constexpr (SRC == SRC_CULL) {
+            if constexpr (IS_CULL(SRC)) {
                 // the segment over_point -> light, walked from the light: apex = light (shared)
                 if (ballot(hit) != 0ull) Bs = make_bundle<true, true>(hit, lightp, lightp, vneg(sdir), sdist);
             }
@@ -1023,7 +1067,7 @@ static hipError_t launch_kernel(const RenderParams &P, dim3 grid, size_t lds_byt
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK), lds_bytes, stream, P, P.isect, P.kind, P.shade,
-                       P.prim, P.bound);
+                       P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound);
     return hipGetLastError();
 }
 template <int SRC, bool REFL, bool REFR>
@@ -1045,6 +1089,7 @@ extern "C" hipError_t rtc_launch_trace(const RenderParams *P, int src, int refl,
     RTC_CASE(SRC_LDS1)
     RTC_CASE(SRC_LDSN)
     RTC_CASE(SRC_CULL)
+    RTC_CASE(SRC_CULL2)
 #undef RTC_CASE
     return hipErrorInvalidValue;
 }

@@ -44,8 +44,9 @@ def make_ctx(rtc, src=None, tile_cap=None):
 
 
 # None = the default (per-wave conservative cull); 0/1/2 = plain brute force with object records
-# through the scalar cache / one LDS tile / LDS tiles of 16 objects; 3 = cull, forced.
-VARIANTS = [(None, None), (0, None), (1, None), (2, 16), (3, None)]
+# through the scalar cache / one LDS tile / LDS tiles of 16 objects; 3 = one-level cull, forced;
+# 4 = two-level cull over the Morton-sorted tables, forced (default for worlds above 256 objects).
+VARIANTS = [(None, None), (0, None), (1, None), (2, 16), (3, None), (4, None)]
 
 
 def camera_rays(rtc, cam, step=1):
