@@ -27,15 +27,17 @@
 
 #define RTC_BLOCK 256
 #define RTC_MAX_STACK 8
-// 2nd argument of __launch_bounds__ = minimum waves per SIMD (caps VGPRs: 4 -> 128, 3 -> 168,
-// 2 -> 256). Measured on the north-star scene (culled flat kernel, 143 VGPRs uncapped):
-// 3 -> 0.139 ms, 4 -> 0.124 ms (40 B/lane of scratch), 5 -> 0.145 ms. Kernels that carry the
-// reflection/refraction frame stack keep 2.
+// 2nd argument of __launch_bounds__ = minimum waves per SIMD (caps VGPRs: 5 -> 96, 4 -> 128,
+// 3 -> 168, 2 -> 256). Measured on the north-star scene (culled flat kernel, built with
+// -disable-machine-licm, 112 VGPRs uncapped): 4 -> 0.120 ms, 5 -> 0.113 ms, 6 -> 0.121 ms.
+// Kernels that carry the reflection/refraction frame stack: see RTC_WAVES_PER_SIMD_STACK.
 #ifndef RTC_WAVES_PER_SIMD
-#define RTC_WAVES_PER_SIMD 4
+#define RTC_WAVES_PER_SIMD 5
 #endif
+// Frame-stack kernels on a reflective 2048x2048 / 100-sphere scene: 2 -> 3.43 ms, 3 -> 2.55,
+// 4 -> 2.22, 5 -> 2.51, 6 -> 2.77.
 #ifndef RTC_WAVES_PER_SIMD_STACK
-#define RTC_WAVES_PER_SIMD_STACK 2
+#define RTC_WAVES_PER_SIMD_STACK 4
 #endif
 
 enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2, SRC_CULL = 3, SRC_CULL2 = 4 };
@@ -640,6 +642,8 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
         const DevIsect *__restrict__ t_isect_s, const uint32_t *__restrict__ t_kind_s, const DevBound *__restrict__ t_bound_s,
         const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound) {
     extern __shared__ double lds_raw[];
+    __shared__ __attribute__((aligned(16))) double stage_f64[PROBE ? 1 : 8 * 32 * 3];      // the tile, canvas layout
+    __shared__ __attribute__((aligned(16))) unsigned char stage_u8[PROBE ? 16 : 8 * 32 * 3];
     const auto &P = KP(P_arg); // set-up view: grid, sizes, mode
     const LdsView L = lds_view(lds_raw, P.tile_cap);
     Tables T;
@@ -979,14 +983,26 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             }
         }
 
-        // Color::average_over (color.rs:128-139): reds = ((0 + c0) + c1) + ... ; the running sums
-        // live in the pixel's own canvas slot between samples, not in registers
-        if (in_range) {
-            const auto &Po = KP(P_arg); // output view
-            double *o = probe ? (Po.out + (size_t)ray_index * 3) : (Po.out + ((size_t)(py - Po.y0) * Po.W + px) * 3);
+        if constexpr (PROBE) {
+            if (in_range) {
+                double *o = KP(P_arg).out + (size_t)ray_index * 3;
+                o[0] = result.x;
+                o[1] = result.y;
+                o[2] = result.z;
+            }
+        } else {
+            // The workgroup's 32x8 pixel tile is staged in LDS (row-major, exactly the canvas layout of
+            // the tile) and written out by the whole workgroup: each tile row is 768 contiguous bytes
+            // of the f64 canvas (six full 128-byte lines) and 96 contiguous bytes of the 8-bit frame,
+            // stored 16 bytes per lane. Direct per-pixel stores (3 x 8 B at a 24 B stride, 3 single
+            // bytes) cost 1.6x the algorithmic bytes in HBM write traffic (rocprofv3 WRITE_SIZE).
+            // Between AA samples the LDS slot also holds Color::average_over's running sums
+            // (color.rs:128-139: reds = ((0 + c0) + c1) + ...).
+            const uint32_t tx = wave * 8u + (lane & 7u), ty = lane >> 3; // position inside the tile
+            double *slot = stage_f64 + (ty * 32u + tx) * 3u;
             if (!traced) result = mk(0., 0., 0.); // Canvas::new BLACK canvas.rs:37-41
             if (nsamples > 1u) {
-                V3 acc = (s == 0u) ? mk(0., 0., 0.) : mk(o[0], o[1], o[2]);
+                V3 acc = (s == 0u) ? mk(0., 0., 0.) : mk(slot[0], slot[1], slot[2]);
                 acc = vadd(acc, result);
                 if (s + 1u == nsamples) {
                     const double l = (double)nsamples;
@@ -994,15 +1010,55 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 }
                 result = acc;
             }
-            o[0] = result.x;
-            o[1] = result.y;
-            o[2] = result.z;
-            if constexpr (!PROBE) {
-                if (Po.out8 && s + 1u == nsamples) {
-                    unsigned char *q = Po.out8 + ((size_t)(py - Po.y0) * Po.W + px) * 3;
+            slot[0] = result.x;
+            slot[1] = result.y;
+            slot[2] = result.z;
+            if (s + 1u == nsamples) {
+                const auto &Po = KP(P_arg); // output view
+                const bool want8 = Po.out8 != nullptr;
+                if (want8) {
+                    unsigned char *q = stage_u8 + (ty * 32u + tx) * 3u;
                     q[0] = scale255(result.x);
                     q[1] = scale255(result.y);
                     q[2] = scale255(result.z);
+                }
+                __syncthreads();
+                const uint32_t px0 = (bid % Po.grid_x) * 32u, py0 = Po.y0 + (bid / Po.grid_x) * 8u;
+                const uint32_t cols = (Po.W - px0 < 32u) ? (Po.W - px0) : 32u;      // valid pixels per tile row
+                const uint32_t rows = (Po.y1 - py0 < 8u) ? (Po.y1 - py0) : 8u;      // valid tile rows
+                // f64 canvas: 16-byte pieces when every tile row is whole and 16-byte aligned
+                const size_t row_bytes = (size_t)Po.W * 24u;
+                const bool wide = cols == 32u && (row_bytes % 16u) == 0 && ((size_t)Po.out % 16u) == 0;
+                if (wide) {
+                    typedef double __attribute__((ext_vector_type(2))) d2;
+                    for (uint32_t c = threadIdx.x; c < rows * 48u; c += RTC_BLOCK) {
+                        const uint32_t r = c / 48u, k = c % 48u;
+                        const d2 v = *reinterpret_cast<const d2 *>(stage_f64 + r * 96u + k * 2u);
+                        char *dst = reinterpret_cast<char *>(Po.out) + (size_t)(py0 + r - Po.y0) * row_bytes + (size_t)px0 * 24u + k * 16u;
+                        *reinterpret_cast<d2 *>(dst) = v;
+                    }
+                } else {
+                    for (uint32_t c = threadIdx.x; c < rows * cols * 3u; c += RTC_BLOCK) {
+                        const uint32_t r = c / (cols * 3u), k = c % (cols * 3u);
+                        Po.out[((size_t)(py0 + r - Po.y0) * Po.W + px0) * 3u + k] = stage_f64[r * 96u + k];
+                    }
+                }
+                if (want8) {
+                    const size_t row8 = (size_t)Po.W * 3u;
+                    const bool wide8 = cols == 32u && (row8 % 16u) == 0 && ((size_t)Po.out8 % 16u) == 0;
+                    if (wide8) {
+                        typedef unsigned __attribute__((ext_vector_type(4))) u4;
+                        for (uint32_t c = threadIdx.x; c < rows * 6u; c += RTC_BLOCK) {
+                            const uint32_t r = c / 6u, k = c % 6u;
+                            const u4 v = *reinterpret_cast<const u4 *>(stage_u8 + r * 96u + k * 16u);
+                            *reinterpret_cast<u4 *>(Po.out8 + (size_t)(py0 + r - Po.y0) * row8 + (size_t)px0 * 3u + k * 16u) = v;
+                        }
+                    } else {
+                        for (uint32_t c = threadIdx.x; c < rows * cols * 3u; c += RTC_BLOCK) {
+                            const uint32_t r = c / (cols * 3u), k = c % (cols * 3u);
+                            Po.out8[((size_t)(py0 + r - Po.y0) * Po.W + px0) * 3u + k] = stage_u8[r * 96u + k];
+                        }
+                    }
                 }
             }
         }
