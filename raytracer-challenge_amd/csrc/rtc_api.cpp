@@ -338,6 +338,20 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
         d.transparency = m.transparency;
         d.refractive_index = m.refractive_index;
         std::memcpy(d.pat_inv, m.pat_inv, sizeof(double) * 12);
+        if (s.kind == RTC_PLANE) {
+            // world_normal = local_normal.transform(inverse_transpose).normalize() with local_normal
+            // (0,1,0) (shape.rs:37-39, 481-483; transform.rs:114-117; vec.rs:65-76): mul/add/sqrt/div
+            // in the reference's order, correctly rounded on the host exactly as on the device
+            // (this file is compiled with -ffp-contract=off)
+            const double *t = d.nt;
+            const double wx = t[0] * 0. + t[1] * 1. + t[2] * 0.;
+            const double wy = t[3] * 0. + t[4] * 1. + t[5] * 0.;
+            const double wz = t[6] * 0. + t[7] * 1. + t[8] * 0.;
+            const double mag = std::sqrt(wx * wx + wy * wy + wz * wz);
+            d.plane_n[0] = wx / mag;
+            d.plane_n[1] = wy / mag;
+            d.plane_n[2] = wz / mag;
+        }
         d.kind = s.kind;
         d.pattern_kind = m.pattern_kind;
         d.world_id = s.world_id;

@@ -7,7 +7,7 @@
 //                   read wave-uniformly through the scalar cache (or staged in LDS tiles).
 //   kind[n]    4 B  RTC_SPHERE / RTC_PLANE / RTC_CUBE.
 //   bound[n]  32 B  f64 world-space bounding sphere (centre, radius) for the conservative cull.
-//   shade[n] 320 B  what shade_hit needs for the ONE object a ray hit: inverse-transpose 3x3,
+//   shade[n] 344 B  what shade_hit needs for the ONE object a ray hit: inverse-transpose 3x3,
 //                   material scalars, pattern; gathered per lane after the hit is known.
 //   isect_s/kind_s/bound_s/orig_s[n], gbound[ceil(n/64)]: the same records in Morton order of the
 //                   bound centres with one bounding sphere per group of 64 — the two-level cull.
@@ -29,6 +29,9 @@ struct DevShade {
     double ambient, diffuse, specular, shininess, reflective, transparency, refractive_index;
     double pat_inv[12]; // rows 0..2 of Pattern.xf_inv
     double pat_a[3], pat_b[3];
+    double plane_n[3];  // planes only: normalize(transform_vector(nt, (0,1,0))) — Shape::normal_at is the
+                        // same for every point of a plane (shape.rs:34-40,481-483), so it is evaluated
+                        // once per object (same operations, same IEEE results) instead of once per hit
     uint32_t kind, pattern_kind, world_id, _pad;
 };
 

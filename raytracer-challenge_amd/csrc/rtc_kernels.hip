@@ -161,6 +161,16 @@ DEVI bool closer(double t, int j, double best, int hidx) { return t < best || (t
 template <class P> DEVI double xpoint_y(P m, V3 p) { return m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7]; }
 template <class P> DEVI double xvector_y(P m, V3 v) { return m[4] * v.x + m[5] * v.y + m[6] * v.z; }
 
+// Plane::intersect_local computes t = -o.y / d.y (shape.rs:467) and every caller then asks whether
+// t >= 0.0. When o.y and d.y are both positive or both negative the quotient is strictly negative —
+// provided it cannot underflow to -0.0 (which WOULD satisfy t >= 0.0): with |o.y| >= 2^-500 and
+// |d.y| <= 2^500 its magnitude is >= 2^-1000. In that case the division (~12 instructions, several
+// of them quarter-rate) can be skipped without changing any result.
+DEVI bool plane_t_certainly_negative(double oy, double dy) {
+    const double lo = 0x1p-500, hi = 0x1p500;
+    return ((oy >= lo && dy > 0. && dy <= hi) || (oy <= -lo && dy < 0. && dy >= -hi));
+}
+
 // World-space ray in, per-kind transform inside (a plane only needs the y row of the inverse).
 template <class P> DEVI void closest_world(uint32_t kind, P m, V3 ro, V3 rd, int j, double &best, int &hidx, int &hroot);
 template <class P> DEVI bool occludes_world(uint32_t kind, P m, V3 ro, V3 rd, double dist);
@@ -216,7 +226,7 @@ DEVI bool occludes(uint32_t kind, V3 o, V3 d, double dist) {
 template <class P> DEVI void closest_world(uint32_t kind, P m, V3 ro, V3 rd, int j, double &best, int &hidx, int &hroot) {
     if (kind == RTC_PLANE) { // shape.rs:462-471
         const double oy = xpoint_y(m, ro), dy = xvector_y(m, rd);
-        if (!(fabs(dy) < RTC_EPSILON)) {
+        if (!(fabs(dy) < RTC_EPSILON) && !plane_t_certainly_negative(oy, dy)) {
             const double t = -oy / dy;
             if (t >= 0.0 && closer(t, j, best, hidx)) { best = t; hidx = j; hroot = 0; }
         }
@@ -227,7 +237,7 @@ template <class P> DEVI void closest_world(uint32_t kind, P m, V3 ro, V3 rd, int
 template <class P> DEVI bool occludes_world(uint32_t kind, P m, V3 ro, V3 rd, double dist) {
     if (kind == RTC_PLANE) {
         const double oy = xpoint_y(m, ro), dy = xvector_y(m, rd);
-        if (fabs(dy) < RTC_EPSILON) return false;
+        if (fabs(dy) < RTC_EPSILON || plane_t_certainly_negative(oy, dy)) return false;
         const double t = -oy / dy;
         return t >= 0.0 && t < dist;
     }
@@ -296,8 +306,8 @@ DEVI bool finite3(V3 v) { return fabs(v.x) < __builtin_inf() && fabs(v.y) < __bu
 
 // SHARED: every active lane's ray starts at `apex` (the camera origin, or the light for shadow
 // segments walked backwards); otherwise the apex is the centroid of the lanes' origins and `rho`
-// their spread. REACH: the rays end after `reach` (shadow segments). The axis is simply the
-// direction of the first active lane (no reduction needed); the half-angle is the largest
+// their spread. REACH: the rays end after `reach` (shadow segments). The axis is the direction of
+// one active lane near the tile centre (no reduction needed); the half-angle is the largest
 // deviation from it.
 template <bool SHARED, bool REACH>
 DEVI Bundle make_bundle(bool active, V3 apex, V3 o, V3 d, double reach) {
@@ -313,17 +323,26 @@ DEVI Bundle make_bundle(bool active, V3 apex, V3 o, V3 d, double reach) {
     }
     const unsigned long long gmask = ballot(good);
     bool off = ballot(active && !good) != 0ull || gmask == 0ull;
-    const int lane0 = gmask ? __builtin_ctzll(gmask) : 0;
+    // axis = direction of a lane near the middle of the 8x8 tile (lane 27 = pixel (3,3)) when it is
+    // active, else the nearest active lane: a centred axis halves the cone's half-angle compared
+    // with a corner lane, i.e. ~4x fewer objects survive the cull
+    const unsigned long long ghi = gmask & ~((1ull << 27) - 1ull);
+    const int lane0 = ghi ? __builtin_ctzll(ghi) : (gmask ? 63 - __builtin_clzll(gmask) : 0);
     const float ax = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fx), lane0));
     const float ay = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fy), lane0));
     const float az = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, fz), lane0));
-    float omc = 0.f, q2 = 0.f; // 1 - cos and sin^2 of the angle to the axis
+    float dotv = 1.f, q2 = 0.f; // cos and sin^2 of the angle to the axis
     if (good) {
-        omc = fmaxf(0.f, 1.f - (ax * fx + ay * fy + az * fz));
+        dotv = ax * fx + ay * fy + az * fz;
         const float cx = ay * fz - az * fy, cy = az * fx - ax * fz, cz = ax * fy - ay * fx;
         q2 = cx * cx + cy * cy + cz * cz;
     }
-    const float cmin = 1.f - wave_max_nonneg(omc), q2max = wave_max_nonneg(q2);
+    const float q2max = wave_max_nonneg(q2);
+    // narrow bundle (every lane within ~45 degrees of the axis): the common case needs only the
+    // sin^2 reduction; the cosine minimum is reduced only for wide bundles
+    const bool narrow = ballot(good && !(dotv > 0.7f)) == 0ull;
+    float cmin = 1.f;
+    if (!narrow) cmin = 1.f - wave_max_nonneg(good ? fmaxf(0.f, 1.f - dotv) : 0.f);
     float rho = 0.f;
     if constexpr (!SHARED) {
         const float cnt = fmaxf(wave_sum(good ? 1.f : 0.f), 1.f);
@@ -348,7 +367,7 @@ DEVI Bundle make_bundle(bool active, V3 apex, V3 o, V3 d, double reach) {
     }
     if (!(cmin > 0.2f)) off = true;
     float sinT, cosT;
-    if (cmin > 0.7f) { // narrow bundle: the cross product resolves small angles, the dot does not
+    if (narrow) { // the cross product resolves small angles, the dot does not
         sinT = __builtin_sqrtf(q2max) * 1.001f + 4e-6f;
         cosT = __builtin_sqrtf(fmaxf(0.f, 1.f - sinT * sinT));
     } else {
@@ -781,14 +800,14 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             if (hit) {
                 point = vadd(ro, vmul(rd, best)); // Ray::position vec.rs:207-209
                 eyev = vneg(rd);
-                // Shape::normal_at shape.rs:34-40 (a plane's local normal ignores the local point)
-                V3 ln;
+                // Shape::normal_at shape.rs:34-40. A plane's normal does not depend on the point: it was
+                // evaluated once per object at rtc_world_create (DevShade::plane_n).
+                V3 ln = mk(0., 1., 0.);
                 const uint32_t kind = S->kind;
-                if (kind == RTC_PLANE) ln = mk(0., 1., 0.);
-                else if (kind == RTC_SPHERE) {
+                if (kind == RTC_SPHERE) {
                     const V3 lp = xpoint(m_obj, point);
                     ln = mk(lp.x - 0., lp.y - 0., lp.z - 0.);
-                } else { // Cube::normal_at_local shape.rs:601-610
+                } else if (kind == RTC_CUBE) { // Cube::normal_at_local shape.rs:601-610
                     const V3 lp = xpoint(m_obj, point);
                     const double ax = fabs(lp.x), ay = fabs(lp.y), az = fabs(lp.z);
                     const double maxc = fmax(ax, fmax(ay, az));
@@ -796,7 +815,8 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     else if (maxc == ay) ln = mk(0., lp.y, 0.);
                     else ln = mk(0., 0., lp.z);
                 }
-                normal = vnormalize(xvector3(S->nt, ln));
+                if (kind == RTC_PLANE) normal = mk(S->plane_n[0], S->plane_n[1], S->plane_n[2]);
+                else normal = vnormalize(xvector3(S->nt, ln));
                 inside = vdot(normal, eyev) < 0.0;
                 if (inside) normal = vneg(normal);
                 over = vadd(point, vmul(normal, RTC_EPSILON));
