@@ -285,7 +285,9 @@ def test_quantised_rows_match_color_scale(rtc, gpu, O, scenes):
     canvas the same launch wrote (exact), and == the oracle's quantisation of its own canvas except
     where pow's last-ulp difference straddles an integer boundary (none expected)."""
     import torch
-    for (w, cam) in (scenes.synthetic(40, 160, 90), scenes.test8(96, 72), scenes.synthetic(12, 64, 48, samples=4)):
+    # 160x90 / 96x72 / 64x48: 16-byte store path; 50x37 and 33x9: partial tiles and the unaligned fallback
+    for (w, cam) in (scenes.synthetic(40, 160, 90), scenes.test8(96, 72), scenes.synthetic(12, 64, 48, samples=4),
+                     scenes.synthetic(10, 50, 37), scenes.synthetic(5, 33, 9, samples=4)):
         dw = gpu.upload(w)
         H, W = cam.vsize, cam.hsize
         f = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda:0")
