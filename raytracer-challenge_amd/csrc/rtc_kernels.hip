@@ -244,6 +244,21 @@ template <class P> DEVI bool occludes_world(uint32_t kind, P m, V3 ro, V3 rd, do
     return occludes(kind, xpoint(m, ro), xvector(m, rd), dist);
 }
 
+// Primary rays: the object-space origin `po` (= transform_point(inv, camera origin)) and the sphere's
+// c = po.po - 1 are the same for every pixel; they come from the per-render table `prim`
+// (k_prep_primary, same arithmetic), so only the direction is transformed here.
+template <class P, class Q> DEVI void closest_prim(uint32_t kind, P m, Q pr, V3 rd, int j, double &best, int &hidx, int &hroot) {
+    if (kind == RTC_PLANE) {
+        const double oy = pr[1], dy = xvector_y(m, rd);
+        if (!(fabs(dy) < RTC_EPSILON) && !plane_t_certainly_negative(oy, dy)) {
+            const double t = -oy / dy;
+            if (t >= 0.0 && closer(t, j, best, hidx)) { best = t; hidx = j; hroot = 0; }
+        }
+    } else {
+        closest_update<true>(kind, mk(pr[0], pr[1], pr[2]), xvector(m, rd), pr[3], j, best, hidx, hroot);
+    }
+}
+
 // ---- wave64 reductions (DPP): inclusive scan inside each row of 16 lanes, then two row
 // broadcasts; the total lands in lane 63. All 64 lanes must execute these (converged code);
 // lanes that do not take part pass the identity.
@@ -472,7 +487,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
                 const uint32_t jj = base + (uint32_t)__builtin_ctzll(mask);
                 mask &= mask - 1ull;
                 const DevIsect *rec = T.isect + jj;
-                if (!f((int)jj, rec->m, T.kind[jj], (const double *)nullptr)) return;
+                if (!f((int)jj, rec->m, T.kind[jj], reinterpret_cast<const double *>(T.prim + jj))) return;
             }
         }
     } else if constexpr (SRC == SRC_CULL2) {
@@ -770,13 +785,9 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 }
             }
             STAMP(2); // primary bundle built
-            if (!IS_CULL(SRC) && shared_origin && first) {
+            if (SRC != SRC_CULL2 && shared_origin && first) {
                 for_each_object<SRC>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
-                    if (tracing) {
-                        const V3 o = mk(pr[0], pr[1], pr[2]);
-                        const V3 d = xvector(m, rd);
-                        closest_update<true>(kind, o, d, pr[3], j, best, hidx, hroot);
-                    }
+                    if (tracing) closest_prim(kind, m, pr, rd, j, best, hidx, hroot);
                     return true;
                 });
             } else {
