@@ -47,6 +47,9 @@ def parse():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo is a rehearsal aid for boxes with fewer GPUs than ranks (tiles hop through host memory)")
     ap.add_argument("--no-overlap", action="store_true", help="wait for each gather before rendering the next frame")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="take the distributed code path (process group, gather, reductions) even with one rank: "
+                         "exercises RCCL on a 1-GPU box")
     ap.add_argument("--gather", default="u8", choices=["u8", "f64"],
                     help="what rank 0 collects: the 8-bit frame (Color::scale, 3 B/pixel - what every file writer of the "
                          "reference consumes) or the raw f64 canvas (24 B/pixel; xGMI-ingest bound at this frame size)")
@@ -98,7 +101,13 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
     gloo = args.dist_backend == "gloo"
-    if world_size > 1:
+    dist_on = world_size > 1 or args.force_dist
+    if args.force_dist and world_size == 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if dist_on:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if gloo:
             dist.init_process_group("gloo")
@@ -121,7 +130,7 @@ def main():
     dworld = ctx.upload(world)
     # two tile / canvas buffers: the RCCL gather of frame k runs (on RCCL's own stream) while frame
     # k+1 renders; a buffer is reused only after the gather that reads or fills it has completed
-    nbuf = 1 if (world_size == 1 or args.no_overlap) else 2
+    nbuf = 1 if (not dist_on or args.no_overlap) else 2
     gdev = torch.device("cpu") if gloo else dev
     # every step renders the f64 canvas tile (resident in HBM, Canvas::get_pixel semantics) AND its
     # 8-bit quantisation; the exchange moves one of the two
@@ -129,7 +138,7 @@ def main():
     tile_bufs = [torch.zeros((rows_max, W, 3), dtype=torch.float64, device=dev) for _ in range(nbuf)]
     tile8_bufs = [torch.zeros((rows_max, W, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     canvases = [torch.empty((world_size * rows_max, W, 3), dtype=gdtype, device=gdev) for _ in range(nbuf)] \
-        if (rank == 0 and world_size > 1) else [None] * nbuf
+        if (rank == 0 and dist_on) else [None] * nbuf
     pending = [None] * nbuf
     state = {"k": 0}
 
@@ -145,7 +154,7 @@ def main():
         dworld.render_rows(cam, y0, y1, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
         if ev:
             ev[1].record(stream)
-        if world_size > 1:
+        if dist_on:
             src = tile8 if args.gather == "u8" else tile
             src = src.cpu() if gloo else src
             work = tiles.gather_tiles(src, canvases[b], world_size, rank, async_op=not args.no_overlap)
@@ -164,10 +173,10 @@ def main():
     ctx.reset_stats()
     # kernel duration by HIP events on the launch stream: every step at N=1 (the roofline figure),
     # every 8th step at N>1 (the host is the bottleneck there; two event records per step are not free)
-    ev_stride = 1 if world_size == 1 else 8
+    ev_stride = 1 if not dist_on else 8
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if k % ev_stride == 0 else None
               for k in range(args.steps)]
-    if world_size > 1:
+    if dist_on:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
@@ -175,7 +184,7 @@ def main():
         step(events[k])
     drain()
     torch.cuda.synchronize(dev)
-    if world_size > 1:
+    if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
@@ -185,7 +194,7 @@ def main():
     last_ms = ctx.last_kernel_ms()
     agg = torch.tensor([elapsed, float(st["rays_primary"]), float(st["rays_shadow"]), float(st["rays_reflect"] + st["rays_refract"]),
                         kernel_ms], dtype=torch.float64, device=torch.device("cpu") if gloo else dev)
-    if world_size > 1:
+    if dist_on:
         tmax = agg[[0, 4]].clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
@@ -221,8 +230,10 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": workload,
-                "objects": len(world), "rows_per_gpu": rows, "parallelism": (f"row-tiles x{world_size} + {'gloo (rehearsal)' if gloo else 'RCCL'} gather to rank 0"
-                                                                          + ("" if args.no_overlap else ", gather k overlapped with render k+1")) if world_size > 1 else "single GPU",
+                "objects": len(world), "rows_per_gpu": rows, "parallelism": (f"row-tiles x{world_size} + {'gloo (rehearsal)' if gloo else 'RCCL'} gather of the "
+                                                                          f"{'8-bit frame (Color::scale)' if args.gather == 'u8' else 'f64 canvas'} to rank 0"
+                                                                          + ("" if args.no_overlap else ", gather k overlapped with render k+1")) if dist_on else "single GPU",
+                "exchange_bytes_per_frame": (W * H * (3 if args.gather == "u8" else 24) * (world_size - 1) // world_size) if dist_on else 0,
                 "rays_per_frame_primary_shadow": int(round(rays_ps / steps)), "rays_per_frame_other": int(round(rays_other / steps)),
             },
             "roofline": {
@@ -247,7 +258,7 @@ def main():
 
     dworld.close()
     ctx.close()
-    if world_size > 1:
+    if dist_on:
         dist.destroy_process_group()
 
 
