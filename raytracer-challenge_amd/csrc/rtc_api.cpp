@@ -49,8 +49,6 @@ struct rtc_world {
     uint32_t *d_orig_s = nullptr;
     DevBound *d_gbound = nullptr;
     uint32_t ngroups = 0;
-    double prim_vinv[12] = {0}; // the camera block `prim` was last computed for
-    bool prim_valid = false;
     rtc_light light{};
     bool any_refl = false, any_refr = false;
 };
@@ -492,15 +490,8 @@ rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camer
     size_t lds_bytes;
     choose_source(ctx, w->n, flags, &src, &P.tile_cap, &lds_bytes);
     P.flags = flags;
-    if (src != SRC_CULL2) {
-        // per-render prologue table; recomputed only when the camera's inverse view matrix changed
-        rtc_world *wm = const_cast<rtc_world *>(w);
-        if (!wm->prim_valid || std::memcmp(wm->prim_vinv, P.vinv, sizeof wm->prim_vinv) != 0) {
-            HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.vinv, ctx->stream));
-            std::memcpy(wm->prim_vinv, P.vinv, sizeof wm->prim_vinv);
-            wm->prim_valid = true;
-        }
-    }
+    // per-render prologue table of the brute-force variants (the culled kernels do not use it)
+    if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.vinv, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
     HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y, lds_bytes, ctx->stream));
     HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));

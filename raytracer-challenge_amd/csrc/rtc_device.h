@@ -45,7 +45,7 @@ struct DevBound {
                           // computable -> never culled
 };
 
-enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PIXELS = 4, CNT_STAMP0 = 8, CNT_N = 16 };
+enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PIXELS = 4, CNT_STAMP0 = 8, CNT_DIAG0 = 16, CNT_N = 24 };
 // Ray counters are kept in CNT_SLOTS replicas (one 64-byte line each); a wave adds to the replica
 // picked by its workgroup id, so no single word sees more than 1/CNT_SLOTS of the atomics. The host
 // sums the replicas (rtc_stats_read).

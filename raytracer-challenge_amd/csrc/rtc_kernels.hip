@@ -53,9 +53,11 @@ struct V3 {
 // phase into counters CNT_STAMP0.. (read with rtc_debug_counters). Never enabled in the shipped
 // library; the stamped build's run time is not meaningful, only the shares are.
 #ifdef RTC_STAMPS
+#define DIAG(i, v) do { diag_c[i] += (v); } while (0)
 #define STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp_t[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define DIAG(i, v) do { } while (0)
 #endif
 
 DEVI V3 mk(double x, double y, double z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
@@ -487,7 +489,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
                 const uint32_t jj = base + (uint32_t)__builtin_ctzll(mask);
                 mask &= mask - 1ull;
                 const DevIsect *rec = T.isect + jj;
-                if (!f((int)jj, rec->m, T.kind[jj], reinterpret_cast<const double *>(T.prim + jj))) return;
+                if (!f((int)jj, rec->m, T.kind[jj], (const double *)nullptr)) return;
             }
         }
     } else if constexpr (SRC == SRC_CULL2) {
@@ -720,6 +722,9 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     uint32_t c_primary = 0, c_shadow = 0, c_reflect = 0, c_refract = 0; // wave-uniform
 #ifdef RTC_STAMPS
     unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // per wave: [0] closest passes, [1] closest passes with an unbounded bundle, [2] exact tests in
+    // closest passes, [3] shadow passes, [4] shadow passes unbounded, [5] exact tests in shadow passes
+    unsigned diag_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     STAMP(0);
 
@@ -785,13 +790,17 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 }
             }
             STAMP(2); // primary bundle built
-            if (SRC != SRC_CULL2 && shared_origin && first) {
+            DIAG(0, ballot(tracing) != 0ull ? 1u : 0u);
+            DIAG(1, (ballot(tracing) != 0ull && B.off) ? 1u : 0u);
+            if (!IS_CULL(SRC) && shared_origin && first) {
                 for_each_object<SRC>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
+                    DIAG(2, 1u);
                     if (tracing) closest_prim(kind, m, pr, rd, j, best, hidx, hroot);
                     return true;
                 });
             } else {
                 for_each_object<SRC>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
+                    DIAG(2, 1u);
                     if (tracing) closest_world(kind, m, ro, rd, j, best, hidx, hroot);
                     return true;
                 });
@@ -895,7 +904,10 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 if (ballot(hit) != 0ull) Bs = make_bundle<true, true>(hit, lightp, lightp, vneg(sdir), sdist);
             }
             STAMP(5); // shadow bundle built
+            DIAG(3, ballot(hit) != 0ull ? 1u : 0u);
+            DIAG(4, (ballot(hit) != 0ull && Bs.off) ? 1u : 0u);
             for_each_object<SRC>(P, T, L, sh_pending, Bs, [&](int j, auto m, uint32_t kind, auto pr) {
+                DIAG(5, 1u);
                 if (sh_pending) {
                     if (occludes_world(kind, m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
                 }
@@ -1108,6 +1120,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             if (npix) atomicAdd(slot + CNT_PIXELS, (unsigned long long)npix);
 #ifdef RTC_STAMPS
             for (int i = 0; i < 7; ++i) atomicAdd(slot + CNT_STAMP0 + i, stamp_t[i + 1] - stamp_t[i]);
+            for (int i = 0; i < 8; ++i) atomicAdd(slot + CNT_DIAG0 + i, (unsigned long long)diag_c[i]);
 #endif
         }
     }

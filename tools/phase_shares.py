@@ -16,7 +16,8 @@ scenes = importlib.import_module(rtc.__name__ + ".scenes")
 import torch  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-w, cam = scenes.synthetic(n, 1920, 1080, with_plane=(n <= 1000))
+refl = len(sys.argv) > 2 and sys.argv[2] == "reflective"
+w, cam = scenes.synthetic(n, 1920, 1080, with_plane=(n <= 1000), reflective=refl)
 ctx = rtc.Context(0)
 dw = ctx.upload(w)
 buf = torch.zeros((1080, 1920, 3), dtype=torch.float64, device="cuda:0")
@@ -26,12 +27,15 @@ for _ in range(3):
 ctx.reset_stats()
 dw.render_rows(cam, 0, 1080, buf.data_ptr())
 ctx.synchronize()
-out = (C.c_ulonglong * 16)()
+out = (C.c_ulonglong * 24)()
 rtc.lib().rtc_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
-rtc.lib().rtc_debug_counters(ctx._h, out, 16)
+rtc.lib().rtc_debug_counters(ctx._h, out, 24)
 names = ["ray generation", "primary bundle", "primary cull + closest hit", "hit record + shadow ray", "shadow bundle",
          "shadow cull + any-hit", "lighting + store"]
 tot = sum(out[8 + i] for i in range(7))
 print(f"objects {len(w)}  kernel_ms(stamped) {ctx.last_kernel_ms():.3f}  waves {out[0] // 64 if out[0] else 0}")
 for i, nm in enumerate(names):
     print(f"  {nm:28s} {out[8 + i] / max(tot, 1) * 100:5.1f} %   {out[8 + i] / 32400:9.0f} ticks/wave")
+d = [out[16 + i] for i in range(8)]
+print(f"per wave: closest passes {d[0] / 32400:.2f} (unbounded bundle {d[1] / 32400:.2f}), exact tests/closest pass {d[2] / max(d[0], 1):.2f}; "
+      f"shadow passes {d[3] / 32400:.2f} (unbounded {d[4] / 32400:.2f}), exact tests/shadow pass {d[5] / max(d[3], 1):.2f}")
