@@ -348,6 +348,51 @@ def test_full_size_north_star_scene(rtc, gpu, O, scenes):
         assert np.max(np.abs(full[y, x] - want)) <= TIGHT_TOL, (x, y)
 
 
+def _full_size_checks(rtc, gpu, O, w, cam, n_samples, seed):
+    """Device-resident full-size render: row bands re-rendered on their own must equal the full
+    frame (compared on the GPU), sampled pixels must match the oracle, ray accounting must add up."""
+    import torch
+    H, W = cam.vsize, cam.hsize
+    dw = gpu.upload(w)
+    full = torch.empty((H, W, 3), dtype=torch.float64, device="cuda:0")
+    band = torch.empty((H // 8, W, 3), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    gpu.reset_stats()
+    dw.render_rows(cam, 0, H, full.data_ptr())
+    gpu.synchronize()
+    st = gpu.stats()
+    assert st["rays_primary"] == W * H and st["pixels"] == W * H and st["rays_shadow"] <= st["rays_primary"] + st["rays_reflect"] + st["rays_refract"]
+    for r in (0, 3, 7):  # three of the eight row tiles an 8-GPU run would render
+        dw.render_rows(cam, r * (H // 8), (r + 1) * (H // 8), band.data_ptr())
+        gpu.synchronize()
+        assert torch.equal(band, full[r * (H // 8):(r + 1) * (H // 8)])
+    rng = np.random.default_rng(seed)
+    xs, ys = rng.integers(0, W, n_samples), rng.integers(0, H, n_samples)
+    got = full[torch.as_tensor(ys, device="cuda:0"), torch.as_tensor(xs, device="cuda:0")].cpu().numpy()
+    arr = w.array()
+    for i in range(n_samples):
+        want = O.color_at(arr, len(w), w.light, rtc.ray_for_pixel(cam, int(xs[i]), int(ys[i])), 5)
+        assert np.max(np.abs(got[i] - want)) <= TIGHT_TOL, (int(xs[i]), int(ys[i]))
+    dw.close()
+    del full, band
+    torch.cuda.empty_cache()
+    return st
+
+
+def test_full_size_c4_reflective_4096(rtc, gpu, O, scenes):
+    """Config C4: 4096x4096, 100 spheres + floor, every surface reflective (depth-5 chains)."""
+    w, cam = scenes.synthetic(100, 4096, 4096, reflective=True)
+    st = _full_size_checks(rtc, gpu, O, w, cam, 400, 21)
+    assert st["rays_reflect"] > 10_000_000 and st["rays_refract"] == 0
+
+
+def test_full_size_c5_8192(rtc, gpu, O, scenes):
+    """Config C5: 8192x8192, 1000 spheres + checker plane (1.6 GB f64 canvas, two-level cull)."""
+    w, cam = scenes.synthetic(1000, 8192, 8192)
+    st = _full_size_checks(rtc, gpu, O, w, cam, 300, 22)
+    assert st["rays_reflect"] == 0
+
+
 def test_ten_thousand_spheres_lds_tiles(rtc, gpu, O, scenes):
     """Config C3 (10 000 spheres: the object table exceeds LDS, so it is walked in tiles): a crop of
     the 1920x1080 frame against the oracle, bit-identical hit records."""
