@@ -28,6 +28,14 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path[:0] = [str(ROOT), str(ROOT / "oracle")]
 
+def baseline_metric():
+    """BASELINE.json's metric string (the headline the line is checked against)."""
+    try:
+        return json.loads((ROOT / "BASELINE.json").read_text())["metric"]
+    except Exception:
+        return "Mrays/sec (primary+shadow), 1920\u00d71080 \u00d7 100 spheres; 1/2/4/8 MI355X"
+
+
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 FP64_PEAK_TINSTR = 39.3      # 78.6 TFLOP/s FP64 vector counts FMA as 2; contraction is off here
 
@@ -216,7 +224,7 @@ def main():
                     ", 1 point light, render_async, SplitMix64 seed 13" + (", reflective depth 5" if args.reflective else ""))
         traffic = measured_traffic(workload) if world_size == 1 else None
         out = {
-            "metric": "Mrays/sec (primary+shadow)",
+            "metric": baseline_metric(),
             "value": round(value, 3),
             "unit": "Mrays/s",
             "n_gpus": world_size,
