@@ -388,8 +388,11 @@ DEVI Bundle make_bundle(bool active, V3 apex, V3 o, V3 d, double reach) {
         sinT = __builtin_sqrtf(q2max) * 1.001f + 4e-6f;
         cosT = __builtin_sqrtf(fmaxf(0.f, 1.f - sinT * sinT));
     } else {
+        // widen through the cosine only and derive the sine from it: (cosT, sinT) must stay a unit
+        // pair. (Inflating the sine on its own SHRINKS the computed distance budget for centres
+        // behind the apex plane, wa < 0 — found by the stress campaign, 1 world in ~25 000.)
         cosT = cmin - 1e-3f;
-        sinT = __builtin_sqrtf(fmaxf(0.f, 1.f - cosT * cosT)) + 1e-3f;
+        sinT = __builtin_sqrtf(fmaxf(0.f, 1.f - cosT * cosT));
     }
     if (!(sinT < 0.98f)) off = true;
     B.off = off;
@@ -409,8 +412,10 @@ DEVI Bundle make_bundle(bool active, V3 apex, V3 o, V3 d, double reach) {
 DEVI bool bundle_touches(const Bundle &B, const DevBound &b) {
     if (B.off) return true;
     if (!(b.r < __builtin_inf())) return true;
-    const double Re = (b.r + B.rho) * 1.00001 + 1e-12;
     const double wx = b.cx - B.px, wy = b.cy - B.py, wz = b.cz - B.pz;
+    // slack: 1e-5 relative on the radius, plus 1e-6 of the centre's L1 distance (>= its Euclidean
+    // distance) for the f32 origin of (axis, cosT, sinT): axis length and cos^2+sin^2 are 1 to ~2e-6
+    const double Re = (b.r + B.rho) * 1.00001 + 1e-6 * (fabs(wx) + fabs(wy) + fabs(wz)) + 1e-12;
     const double d2 = wx * wx + wy * wy + wz * wz;
     if (d2 <= Re * Re) return true;
     const double wa = wx * B.ax + wy * B.ay + wz * B.az;
@@ -423,6 +428,25 @@ DEVI bool bundle_touches(const Bundle &B, const DevBound &b) {
     if (rhs < 0.) return false;
     const double perp2 = d2 - wa * wa * 1.00001;
     return !(perp2 * (B.cosT * B.cosT) > rhs * rhs);   // NaN-safe: keep the object unless provably far
+}
+
+// Per-lane prefilter for INCOHERENT rays (reflection / refraction): can THIS lane's ray, for some
+// t >= 0, touch the object's bounding sphere? false => the exact test would find no entry with
+// t >= 0 for this lane. ~22 f64 instructions against 54+ for the exact test; the exact test is
+// then issued only if some lane of the wave passes. (For coherent primary / shadow bundles the
+// wave-level cull already leaves 1-2 candidates per pass and this filter would only add work.)
+DEVI bool ray_touches(V3 o, V3 d, const DevBound &b) {
+    if (!(b.r < __builtin_inf())) return true;
+    const double R = b.r * 1.000001 + 1e-12;
+    const double wx = b.cx - o.x, wy = b.cy - o.y, wz = b.cz - o.z;
+    const double ww = wx * wx + wy * wy + wz * wz;
+    const double R2 = R * R;
+    if (ww <= R2) return true;                       // origin inside the sphere
+    const double proj = wx * d.x + wy * d.y + wz * d.z;
+    if (proj < 0.) return false;                      // sphere wholly behind the origin (ww > R^2)
+    const double dd = d.x * d.x + d.y * d.y + d.z * d.z;
+    // perp^2 * dd = ww*dd - proj^2 <= R^2 * dd ; the slack covers the cancellation error
+    return !(ww * dd - proj * proj > R2 * dd + 1e-11 * ww * dd); // NaN-safe: keep unless provably far
 }
 
 // ---- wave-uniform object loop ------------------------------------------------------------
@@ -472,8 +496,9 @@ DEVI void stage_tile(const Tables &T, const LdsView &L, uint32_t base, uint32_t 
     for (uint32_t e = threadIdx.x; e < cnt; e += RTC_BLOCK) L.kind[e] = T.kind[base + e];
 }
 
-template <int SRC, class PP, class F>
-DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool lane_needs, const Bundle &B, F &&f) {
+template <int SRC, bool LANE_FILTER = false, class PP, class F>
+DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool lane_needs, const Bundle &B, F &&f,
+                          V3 fro = V3{0., 0., 0.}, V3 frd = V3{0., 0., 0.}) {
     if constexpr (SRC == SRC_CULL) {
         // One-level cull (small worlds): 64 objects at a time, each lane tests one object's sphere
         // against the wave's bundle; the ballot mask is walked in ascending (= insertion) order and
@@ -488,6 +513,9 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
             while (mask) {
                 const uint32_t jj = base + (uint32_t)__builtin_ctzll(mask);
                 mask &= mask - 1ull;
+                if constexpr (LANE_FILTER) {
+                    if (ballot(lane_needs && ray_touches(fro, frd, T.bound[jj])) == 0ull) continue;
+                }
                 const DevIsect *rec = T.isect + jj;
                 if (!f((int)jj, rec->m, T.kind[jj], (const double *)nullptr)) return;
             }
@@ -514,6 +542,9 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
                 while (mask) {
                     const uint32_t jj = base + (uint32_t)__builtin_ctzll(mask);
                     mask &= mask - 1ull;
+                    if constexpr (LANE_FILTER) {
+                        if (ballot(lane_needs && ray_touches(fro, frd, T.bound_s[jj])) == 0ull) continue;
+                    }
                     const DevIsect *rec = T.isect_s + jj;
                     if (!f((int)T.orig_s[jj], rec->m, T.kind_s[jj], (const double *)nullptr)) return;
                 }
@@ -787,6 +818,12 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 if (ballot(tracing) != 0ull) {
                     if (shared_origin && first) B = make_bundle<true, false>(tracing, cam_origin, ro, rd, 0.);
                     else B = make_bundle<false, false>(tracing, cam_origin, ro, rd, 0.);
+#ifdef RTC_NO_SECONDARY_CULL
+                    if (!(shared_origin && first)) B.off = true;
+#endif
+#ifdef RTC_NO_PRIMARY_CULL
+                    if (shared_origin && first) B.off = true;
+#endif
                 }
             }
             STAMP(2); // primary bundle built
@@ -798,6 +835,15 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     if (tracing) closest_prim(kind, m, pr, rd, j, best, hidx, hroot);
                     return true;
                 });
+#ifndef RTC_NO_LANE_FILTER
+            } else if (IS_CULL(SRC) && REFL && !(shared_origin && first)) {
+                // reflection / refraction rays: incoherent, per-lane prefilter before the exact test
+                for_each_object<SRC, true>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
+                    DIAG(2, 1u);
+                    if (tracing) closest_world(kind, m, ro, rd, j, best, hidx, hroot);
+                    return true;
+                }, ro, rd);
+#endif
             } else {
                 for_each_object<SRC>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
                     DIAG(2, 1u);
@@ -902,6 +948,9 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             if constexpr (IS_CULL(SRC)) {
                 // the segment over_point -> light, walked from the light: apex = light (shared)
                 if (ballot(hit) != 0ull) Bs = make_bundle<true, true>(hit, lightp, lightp, vneg(sdir), sdist);
+#ifdef RTC_NO_SHADOW_CULL
+                Bs.off = true;
+#endif
             }
             STAMP(5); // shadow bundle built
             DIAG(3, ballot(hit) != 0ull ? 1u : 0u);
