@@ -117,7 +117,7 @@ uint64_t morton_key(const DevBound &b, const double lo[3], const double hi[3]) {
 // the farthest transformed corner (cubes), inflated by 1e-6; anything not clearly well-conditioned
 // gets r = +inf and is simply never culled.
 DevBound bound_of(const rtc_shape &s) {
-    DevBound b{0., 0., 0., INFINITY};
+    DevBound b{0., 0., 0., INFINITY, 0., 0.};
     if (s.kind == RTC_PLANE) return b;
     const double *m = s.inv;
     const double a[3][3] = {{m[0], m[1], m[2]}, {m[4], m[5], m[6]}, {m[8], m[9], m[10]}};
@@ -198,7 +198,14 @@ DevBound bound_of(const rtc_shape &s) {
     const double cn = std::sqrt(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
     const double r = std::sqrt(r2) * (1. + 1e-6) + 1e-9 * (1. + cn) + 1e-7 * fmaxabs;
     if (!std::isfinite(r) || !std::isfinite(cn)) return b;
+    double na2 = 0.; // ||A||_F^2 >= ||A||_2^2
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) na2 += a[i][j] * a[i][j];
+    const double k = 0.75e-14 * na2;
+    if (!std::isfinite(k)) return b;
     b.cx = c[0]; b.cy = c[1]; b.cz = c[2]; b.r = r;
+    b.k = k;
+    b.cn = cn;
     return b;
 }
 
@@ -379,22 +386,24 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
     std::vector<uint32_t> kind_s(na, 0), orig_s(na, 0);
     std::vector<DevBound> bound_s(na), gbound(ngroups ? ngroups : 1);
     std::memset(isect_s.data(), 0, sizeof(DevIsect) * na);
-    for (uint32_t i = 0; i < na; ++i) bound_s[i] = DevBound{0., 0., 0., INFINITY};
+    for (uint32_t i = 0; i < na; ++i) bound_s[i] = DevBound{0., 0., 0., INFINITY, 0., 0.};
     for (uint32_t i = 0; i < n; ++i) {
         isect_s[i] = isect[order[i]];
         kind_s[i] = kind[order[i]];
         bound_s[i] = bound[order[i]];
         orig_s[i] = order[i];
     }
-    gbound[0] = DevBound{0., 0., 0., INFINITY};
+    gbound[0] = DevBound{0., 0., 0., INFINITY, 0., 0.};
     for (uint32_t g = 0; g < ngroups; ++g) {
         const uint32_t a = g * 64u, b = (a + 64u < n) ? a + 64u : n;
-        DevBound gb{0., 0., 0., INFINITY};
+        DevBound gb{0., 0., 0., INFINITY, 0., 0.};
         bool finite = true;
-        double cx = 0., cy = 0., cz = 0.;
+        double cx = 0., cy = 0., cz = 0., kmax = 0., cnmax = 0.;
         for (uint32_t i = a; i < b; ++i) {
             if (!std::isfinite(bound_s[i].r)) { finite = false; break; }
             cx += bound_s[i].cx; cy += bound_s[i].cy; cz += bound_s[i].cz;
+            kmax = std::fmax(kmax, bound_s[i].k);
+            cnmax = std::fmax(cnmax, bound_s[i].cn);
         }
         if (finite && b > a) {
             const double cnt = (double)(b - a);
@@ -405,7 +414,11 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
                 r = std::fmax(r, std::sqrt(dx * dx + dy * dy + dz * dz) + bound_s[i].r);
             }
             r = r * (1. + 1e-9) + 1e-12;
-            if (std::isfinite(r) && std::isfinite(cx) && std::isfinite(cy) && std::isfinite(cz)) gb = DevBound{cx, cy, cz, r};
+            // rounding inflation of the group: members' radii inflate by at most
+            // r_i*k_i*D_i*(cn_i + D_i) with D_i <= D_group + r_group; folded into the group's k/cn
+            // conservatively: k = max k_i, cn = max cn_i + r (so that D_group + cn covers D_i + cn_i)
+            if (std::isfinite(r) && std::isfinite(cx) && std::isfinite(cy) && std::isfinite(cz))
+                gb = DevBound{cx, cy, cz, r, kmax * 4., cnmax + 2. * r};
         }
         gbound[g] = gb;
     }

@@ -6,7 +6,7 @@
 //                   Shape::intersect needs (vec.rs:211-214, transform.rs:107-128);
 //                   read wave-uniformly through the scalar cache (or staged in LDS tiles).
 //   kind[n]    4 B  RTC_SPHERE / RTC_PLANE / RTC_CUBE.
-//   bound[n]  32 B  f64 world-space bounding sphere (centre, radius) for the conservative cull.
+//   bound[n]  48 B  f64 world-space bounding sphere (centre, radius) + rounding-inflation terms.
 //   shade[n] 344 B  what shade_hit needs for the ONE object a ray hit: inverse-transpose 3x3,
 //                   material scalars, pattern; gathered per lane after the hit is known.
 //   isect_s/kind_s/bound_s/orig_s[n], gbound[ceil(n/64)]: the same records in Morton order of the
@@ -43,7 +43,21 @@ struct DevPrim {
 struct DevBound {
     double cx, cy, cz, r; // world-space bounding sphere; r = +inf: unbounded (planes) or not
                           // computable -> never culled
+    double k;             // 0.75e-14 * ||A||_F^2 (A = 3x3 of the stored inverse): rounding inflation
+    double cn;            // |centre|: see the note on rounding below
 };
+// Rounding note. The cull must never drop an object for which the REFERENCE ARITHMETIC reports an
+// intersection — including intersections that exist only because of rounding. The sphere test
+// evaluates disc = b*b - 4*a*c with b^2 and 4ac of size ~4a|o'|^2 (o' = object-space ray origin);
+// far origins and thin objects (large ||A||) make the f64 error exceed the true discriminant and
+// the reference "hits" an object the ray geometrically misses (seen: origin 1e6 away, ||A||_F^2 =
+// 1.7e5, hit reported 2.1 radii from the centre). Error analysis of the reference's expression
+// order gives: a root can be reported only if the line passes within object-space distance
+//   R_eff^2 <= 1 + eps*|o'|*(16*S + 13*|o'|),  |o'| <= ||A||*D,  S = ||A||*(|o| + |c|),
+// D = distance of the ray origin from the centre; every reported root lies inside that inflated
+// sphere. With eps = 2^-52, |o| <= |c| + D and sqrt(1+x) <= 1 + x/2 the world-space radius to test
+// is r * (1 + k * D * (cn + D)) with k = 0.75e-14 * ||A||_F^2 (any upper bound of D may be used).
+// For ordinary scenes the factor is 1 + 1e-9.
 
 enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PIXELS = 4, CNT_STAMP0 = 8, CNT_DIAG0 = 16, CNT_N = 24 };
 // Ray counters are kept in CNT_SLOTS replicas (one 64-byte line each); a wave adds to the replica

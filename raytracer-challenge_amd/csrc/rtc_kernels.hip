@@ -309,6 +309,9 @@ struct Bundle {
     double cosT, sinT;   // half-angle, already widened
     double rho;          // origin spread around the apex
     double tmax;         // reach along the rays (inf: unbounded)
+    double spread;       // upper bound of the distance apex -> the ORIGIN the exact test uses (0 for
+                         // primary rays, rho for secondary rays, tmax for shadow segments, whose
+                         // exact rays start at the far end)
     bool off;            // bundle could not be bounded: every object is a candidate
 };
 
@@ -401,6 +404,9 @@ DEVI Bundle make_bundle(bool active, V3 apex, V3 o, V3 d, double reach) {
     B.cosT = uniform_f64((double)cosT); B.sinT = uniform_f64((double)sinT);
     B.rho = uniform_f64((double)rho);
     B.tmax = uniform_f64((double)tmax);
+    B.spread = REACH ? B.tmax : B.rho;
+    if (!(B.spread < 1e300)) off = true; // shadow segment of unbounded length: do not cull
+    B.off = off;
     return B;
 }
 
@@ -413,9 +419,13 @@ DEVI bool bundle_touches(const Bundle &B, const DevBound &b) {
     if (B.off) return true;
     if (!(b.r < __builtin_inf())) return true;
     const double wx = b.cx - B.px, wy = b.cy - B.py, wz = b.cz - B.pz;
+    // rounding inflation of the radius (rtc_device.h, DevBound): D <= |C - apex|_1 + spread
+    const double l1 = fabs(wx) + fabs(wy) + fabs(wz);
+    const double Dub = l1 + B.spread;
+    const double r_eff = b.r + b.r * (b.k * Dub * (b.cn + Dub));
     // slack: 1e-5 relative on the radius, plus 1e-6 of the centre's L1 distance (>= its Euclidean
     // distance) for the f32 origin of (axis, cosT, sinT): axis length and cos^2+sin^2 are 1 to ~2e-6
-    const double Re = (b.r + B.rho) * 1.00001 + 1e-6 * (fabs(wx) + fabs(wy) + fabs(wz)) + 1e-12;
+    const double Re = (r_eff + B.rho) * 1.00001 + 1e-6 * l1 + 1e-12;
     const double d2 = wx * wx + wy * wy + wz * wz;
     if (d2 <= Re * Re) return true;
     const double wa = wx * B.ax + wy * B.ay + wz * B.az;
@@ -437,8 +447,9 @@ DEVI bool bundle_touches(const Bundle &B, const DevBound &b) {
 // wave-level cull already leaves 1-2 candidates per pass and this filter would only add work.)
 DEVI bool ray_touches(V3 o, V3 d, const DevBound &b) {
     if (!(b.r < __builtin_inf())) return true;
-    const double R = b.r * 1.000001 + 1e-12;
     const double wx = b.cx - o.x, wy = b.cy - o.y, wz = b.cz - o.z;
+    const double Dub = fabs(wx) + fabs(wy) + fabs(wz); // >= |C - o|
+    const double R = (b.r + b.r * (b.k * Dub * (b.cn + Dub))) * 1.000001 + 1e-12; // rounding inflation, see DevBound
     const double ww = wx * wx + wy * wy + wz * wz;
     const double R2 = R * R;
     if (ww <= R2) return true;                       // origin inside the sphere
