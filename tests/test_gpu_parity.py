@@ -243,6 +243,23 @@ def test_cull_is_exact_on_adversarial_scenes(rtc, gpu, O):
         dw.close()
 
 
+@pytest.mark.parametrize("seed", [701683, 755117])
+def test_cull_regressions_found_by_the_stress_campaign(rtc, gpu, O, seed):
+    """Two worlds out of ~85 000 random ones (tools/stress_parity.py) once differed from brute force:
+    701683 — a wide shadow bundle whose sine had been inflated independently of its cosine;
+    755117 — a shadow ray starting 1.1e6 units away that the REFERENCE arithmetic reports as hitting
+    a thin ellipsoid it geometrically misses by two radii (catastrophic cancellation in b*b - 4ac):
+    the cull has to keep such objects, so the bound radius is inflated by the quadratic's error
+    bound (rtc_device.h, DevBound)."""
+    w, cam = adversarial_scene(rtc, seed)
+    dw = gpu.upload(w)
+    got, st = dw.render(cam, rtc.MODE_RENDER_ASYNC, with_stats=True)
+    brute, sb = dw.render(cam, rtc.MODE_RENDER_ASYNC, flags=1, with_stats=True)
+    want, ost = O.render(w.array(), len(w), w.light, cam, mode=1, nthreads=8, want_stats=True)
+    assert np.array_equal(got, brute) and st == sb == ost
+    assert np.max(np.abs(got - want)) <= TIGHT_TOL
+
+
 def test_jamis_scene_config1(rtc, gpu, O):
     """Config 1: the chapter-11 room (jamis.yml vocabulary) at 100x50 -> canvas -> PPM."""
     path = os.path.join(os.path.dirname(rtc.__file__), "data", "reflect_refract.yml")
