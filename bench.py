@@ -147,6 +147,7 @@ def main():
     tile8_bufs = [torch.zeros((rows_max, W, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     canvases = [torch.empty((world_size * rows_max, W, 3), dtype=gdtype, device=gdev) for _ in range(nbuf)] \
         if (rank == 0 and dist_on) else [None] * nbuf
+    bands = [tiles.band_views(c, world_size) if c is not None else None for c in canvases]
     pending = [None] * nbuf
     state = {"k": 0}
 
@@ -165,7 +166,7 @@ def main():
         if dist_on:
             src = tile8 if args.gather == "u8" else tile
             src = src.cpu() if gloo else src
-            work = tiles.gather_tiles(src, canvases[b], world_size, rank, async_op=not args.no_overlap)
+            work = tiles.gather_tiles(src, canvases[b], world_size, rank, async_op=not args.no_overlap, bands=bands[b])
             if work is not None:
                 pending[b] = work
 

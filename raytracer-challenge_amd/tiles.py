@@ -19,14 +19,20 @@ def row_range(height: int, world_size: int, rank: int) -> tuple[int, int]:
     return y0, min(height, y0 + per)
 
 
-def gather_tiles(tile, canvas, world_size: int, rank: int, group=None, async_op: bool = False):
+def band_views(canvas, world_size: int):
+    """The per-rank bands of the gathered canvas as a list of views (build once, reuse every frame)."""
+    return list(canvas.chunk(world_size, dim=0))
+
+
+def gather_tiles(tile, canvas, world_size: int, rank: int, group=None, async_op: bool = False, bands=None):
     """Gather every rank's (rows_per_rank, W, 3) tile into `canvas` ((world_size*rows_per_rank, W, 3))
     on rank 0. Bands are contiguous, so the gather lands each tile at its final place. With
-    async_op=True returns the work handle (wait() before reusing `tile` / reading `canvas`)."""
+    async_op=True returns the work handle (wait() before reusing `tile` / reading `canvas`).
+    `bands` = band_views(canvas, world_size) prebuilt by the caller (saves host time per frame)."""
     import torch.distributed as dist
 
     if rank == 0:
-        return dist.gather(tile, list(canvas.chunk(world_size, dim=0)), dst=0, group=group, async_op=async_op)
+        return dist.gather(tile, bands if bands is not None else band_views(canvas, world_size), dst=0, group=group, async_op=async_op)
     return dist.gather(tile, None, dst=0, group=group, async_op=async_op)
 
 
