@@ -151,18 +151,14 @@ def main():
     pending = [None] * nbuf
     state = {"k": 0}
 
-    def step(ev=None):
+    def step():
         b = state["k"] % nbuf
         state["k"] += 1
         if pending[b] is not None:
             pending[b].wait()       # current stream waits for the gather that last used buffer b
             pending[b] = None
         tile, tile8 = tile_bufs[b], tile8_bufs[b]
-        if ev:
-            ev[0].record(stream)
         dworld.render_rows(cam, y0, y1, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
-        if ev:
-            ev[1].record(stream)
         if dist_on:
             src = tile8 if args.gather == "u8" else tile
             src = src.cpu() if gloo else src
@@ -180,17 +176,14 @@ def main():
         step()
     drain()
     ctx.reset_stats()
-    # kernel duration by HIP events on the launch stream: every step at N=1 (the roofline figure),
-    # every 8th step at N>1 (the host is the bottleneck there; two event records per step are not free)
-    ev_stride = 1 if not dist_on else 8
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) if k % ev_stride == 0 else None
-              for k in range(args.steps)]
+    # kernel duration: every launch carries its own pair of HIP events on the launch stream
+    # (hipExtLaunchKernel start/stop events inside rtc_render_rows, read back after the timed region)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(events[k])
+        step()
     drain()
     torch.cuda.synchronize(dev)
     if dist_on:
@@ -198,9 +191,9 @@ def main():
     elapsed = time.perf_counter() - t0
 
     st = ctx.stats()
-    timed = [e for e in events if e is not None]
-    kernel_ms = sum(a.elapsed_time(b) for a, b in timed) / max(1, len(timed))
-    last_ms = ctx.last_kernel_ms()
+    times = ctx.kernel_times_ms(min(args.steps, 1024))   # the timed steps (the newest 1024 of them if more)
+    kernel_ms = float(times.mean()) if len(times) else 0.0
+    last_ms = float(times[-1]) if len(times) else 0.0
     agg = torch.tensor([elapsed, float(st["rays_primary"]), float(st["rays_shadow"]), float(st["rays_reflect"] + st["rays_refract"]),
                         kernel_ms], dtype=torch.float64, device=torch.device("cpu") if gloo else dev)
     if dist_on:
@@ -250,6 +243,7 @@ def main():
                 "unit": "GB/s", "frac": round(abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                 "traffic": int(traffic[0]) if traffic else None, "traffic_source": traffic[1] if traffic else None,
                 "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": round(kernel_ms, 5), "kernel_ms_last_launch": round(last_ms, 5),
+                "kernel_launches_timed": int(len(times)),
                 "note": "one launch writes the f64 canvas tile once and reads the ~50 KB scene; the kernel is f64-VALU/latency bound, see DESIGN.md",
             },
             "valu_roofline": {

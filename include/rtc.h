@@ -262,8 +262,13 @@ rtc_status  rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *c
 /* Ray counters accumulated since the last reset (synchronises the stream). */
 rtc_status  rtc_stats_read(rtc_context *ctx, rtc_stats *out);
 rtc_status  rtc_stats_reset(rtc_context *ctx);
-/* Duration in ms of the most recent rtc_render_rows launch measured with HIP events on the
- * context stream (synchronises). */
+/* Kernel timing. Every rtc_render_rows launch carries its own pair of HIP events that receive
+ * the dispatch's begin and end timestamps on the context stream (hipExtLaunchKernel: no marker
+ * packets, the same quantity rocprofv3's kernel trace reports). The context keeps the most
+ * recent 1024 pairs. rtc_kernel_times_ms writes the durations (ms) of the latest min(cap, kept)
+ * launches, oldest first, and their number to *n; rtc_last_kernel_ms is the newest one alone
+ * (RTC_ERR_ARG if nothing was launched yet). Both wait for the newest launch to finish. */
+rtc_status  rtc_kernel_times_ms(rtc_context *ctx, float *out, uint32_t cap, uint32_t *n);
 rtc_status  rtc_last_kernel_ms(rtc_context *ctx, float *ms);
 
 /* World::color_at(ray, remaining) (shape.rs:702-710) for `n` arbitrary host rays

@@ -309,6 +309,13 @@ class Context:
         _check(lib().rtc_last_kernel_ms(self._h, C.byref(ms)), "rtc_last_kernel_ms")
         return ms.value
 
+    def kernel_times_ms(self, last: int = 1024) -> np.ndarray:
+        """Durations (ms) of the most recent `last` render launches, oldest first (include/rtc.h)."""
+        buf = (C.c_float * max(1, last))()
+        n = C.c_uint32()
+        _check(lib().rtc_kernel_times_ms(self._h, buf, last, C.byref(n)), "rtc_kernel_times_ms")
+        return np.frombuffer(buf, dtype=np.float32, count=n.value).copy()
+
     def device_arith(self, op: int, a: np.ndarray, b: np.ndarray | None = None) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.float64)
         bb = np.ascontiguousarray(b if b is not None else a, dtype=np.float64)

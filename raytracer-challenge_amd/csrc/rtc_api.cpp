@@ -16,7 +16,7 @@
 #include "rtc_device.h"
 
 extern "C" hipError_t rtc_launch_trace(const RenderParams *P, int src, int refl, int refr, uint32_t nblocks,
-                                       size_t lds_bytes, hipStream_t stream);
+                                       size_t lds_bytes, hipStream_t stream, hipEvent_t e0, hipEvent_t e1);
 extern "C" hipError_t rtc_launch_prep(const DevIsect *isect, DevPrim *prim, uint32_t n, const double vinv[12],
                                       hipStream_t stream);
 extern "C" hipError_t rtc_launch_arith(uint32_t op, const double *a, const double *b, uint32_t n, double *out,
@@ -28,8 +28,10 @@ struct rtc_context {
     int device = -1;
     hipStream_t stream = nullptr;
     unsigned long long *d_counters = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    bool have_timing = false;
+    // ring of (begin, end) event pairs, one per k_trace launch of rtc_render_rows (created on first use)
+    static constexpr uint32_t EV_RING = 1024;
+    hipEvent_t ev[EV_RING][2] = {};
+    uint64_t launches = 0;
     int force_src = -1;   // RTC_SRC env override (experiments)
     uint32_t tile_cap = 512;
 };
@@ -257,8 +259,7 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
     ctx->stream = static_cast<hipStream_t>(stream); // NULL = the device's default stream
 
     if (hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * CNT_N * CNT_SLOTS) != hipSuccess ||
-        hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N * CNT_SLOTS, ctx->stream) != hipSuccess ||
-        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N * CNT_SLOTS, ctx->stream) != hipSuccess) {
         rtc_context_destroy(ctx);
         return RTC_ERR_DEVICE;
     }
@@ -279,8 +280,9 @@ void rtc_context_destroy(rtc_context *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (auto &pair : ctx->ev)
+        for (hipEvent_t e : pair)
+            if (e) (void)hipEventDestroy(e);
     delete ctx;
 }
 
@@ -505,10 +507,12 @@ rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camer
     P.flags = flags;
     // per-render prologue table of the brute-force variants (the culled kernels do not use it)
     if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.vinv, ctx->stream));
-    HIP_TRY(hipEventRecord(ctx->ev0, ctx->stream));
-    HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y, lds_bytes, ctx->stream));
-    HIP_TRY(hipEventRecord(ctx->ev1, ctx->stream));
-    ctx->have_timing = true;
+    hipEvent_t *pair = ctx->ev[ctx->launches % rtc_context::EV_RING];
+    if (!pair[0]) HIP_TRY(hipEventCreate(&pair[0]));
+    if (!pair[1]) HIP_TRY(hipEventCreate(&pair[1]));
+    HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y, lds_bytes, ctx->stream,
+                             pair[0], pair[1]));
+    ++ctx->launches;
     return RTC_OK;
 }
 
@@ -552,12 +556,27 @@ rtc_status rtc_stats_reset(rtc_context *ctx) {
     return RTC_OK;
 }
 
-rtc_status rtc_last_kernel_ms(rtc_context *ctx, float *ms) {
-    if (!ctx || !ms || !ctx->have_timing) return RTC_ERR_ARG;
+rtc_status rtc_kernel_times_ms(rtc_context *ctx, float *out, uint32_t cap, uint32_t *n) {
+    if (!ctx || !n || (cap && !out)) return RTC_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    HIP_TRY(hipEventSynchronize(ctx->ev1));
-    HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    const uint64_t have = ctx->launches < rtc_context::EV_RING ? ctx->launches : rtc_context::EV_RING;
+    const uint64_t take = have < cap ? have : cap;
+    *n = (uint32_t)take;
+    if (take == 0) return RTC_OK;
+    HIP_TRY(hipEventSynchronize(ctx->ev[(ctx->launches - 1) % rtc_context::EV_RING][1]));
+    for (uint64_t k = 0; k < take; ++k) {
+        hipEvent_t *pair = ctx->ev[(ctx->launches - take + k) % rtc_context::EV_RING];
+        HIP_TRY(hipEventElapsedTime(&out[k], pair[0], pair[1]));
+    }
     return RTC_OK;
+}
+
+rtc_status rtc_last_kernel_ms(rtc_context *ctx, float *ms) {
+    uint32_t n = 0;
+    if (!ctx || !ms) return RTC_ERR_ARG;
+    const rtc_status st = rtc_kernel_times_ms(ctx, ms, 1, &n);
+    if (st != RTC_OK) return st;
+    return n == 1 ? RTC_OK : RTC_ERR_ARG;
 }
 
 rtc_status rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode, uint32_t flags,
@@ -609,7 +628,8 @@ rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays
         size_t lds_bytes;
         choose_source(ctx, w->n, flags, &src, &P.tile_cap, &lds_bytes);
         P.flags = flags;
-        if (rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x, lds_bytes, ctx->stream) != hipSuccess)
+        if (rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x, lds_bytes, ctx->stream, nullptr,
+                             nullptr) != hipSuccess)
             st = RTC_ERR_DEVICE;
     }
     if (st == RTC_OK && hipMemcpyAsync(rgb, d_rgb, sizeof(double) * 3 * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)

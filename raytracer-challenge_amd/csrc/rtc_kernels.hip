@@ -21,6 +21,7 @@
 //    frame stack; colours are folded back in the reference's nesting order.
 //  * no MFMA anywhere: there is no dense contraction on this path.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include "rtc.h"
 #include "rtc_device.h"
@@ -1220,30 +1221,33 @@ __global__ void k_arith(uint32_t op, const double *a, const double *b, uint32_t 
 
 // ---- launchers (called from rtc_api.cpp) --------------------------------------------------
 template <int SRC, bool REFL, bool REFR, bool PROBE>
-static hipError_t launch_kernel(const RenderParams &P, dim3 grid, size_t lds_bytes, hipStream_t stream) {
+static hipError_t launch_kernel(const RenderParams &P, dim3 grid, size_t lds_bytes, hipStream_t stream, hipEvent_t e0,
+                                hipEvent_t e1) {
     if (lds_bytes > 48 * 1024) { // more dynamic LDS than the default limit: opt in (up to 160 KiB per CU on gfx950)
         const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_trace<SRC, REFL, REFR, PROBE>),
                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK), lds_bytes, stream, P, P.isect, P.kind, P.shade,
-                       P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound);
+    // e0/e1 (may be NULL) receive the dispatch's own begin/end timestamps: no marker packets on the stream
+    hipExtLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK), lds_bytes, stream, e0, e1, 0, P, P.isect,
+                          P.kind, P.shade, P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound);
     return hipGetLastError();
 }
 template <int SRC, bool REFL, bool REFR>
-static hipError_t launch_one(const RenderParams &P, dim3 grid, size_t lds_bytes, hipStream_t stream) {
-    if (P.rays != nullptr) return launch_kernel<SRC, REFL, REFR, true>(P, grid, lds_bytes, stream);
-    return launch_kernel<SRC, REFL, REFR, false>(P, grid, lds_bytes, stream);
+static hipError_t launch_one(const RenderParams &P, dim3 grid, size_t lds_bytes, hipStream_t stream, hipEvent_t e0,
+                             hipEvent_t e1) {
+    if (P.rays != nullptr) return launch_kernel<SRC, REFL, REFR, true>(P, grid, lds_bytes, stream, e0, e1);
+    return launch_kernel<SRC, REFL, REFR, false>(P, grid, lds_bytes, stream, e0, e1);
 }
 
 extern "C" hipError_t rtc_launch_trace(const RenderParams *P, int src, int refl, int refr, uint32_t nblocks,
-                                       size_t lds_bytes, hipStream_t stream) {
+                                       size_t lds_bytes, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     const dim3 grid(nblocks);
 #define RTC_CASE(S)                                                                            \
     if (src == S) {                                                                            \
-        if (refr) return launch_one<S, true, true>(*P, grid, lds_bytes, stream);               \
-        if (refl) return launch_one<S, true, false>(*P, grid, lds_bytes, stream);              \
-        return launch_one<S, false, false>(*P, grid, lds_bytes, stream);                       \
+        if (refr) return launch_one<S, true, true>(*P, grid, lds_bytes, stream, e0, e1);               \
+        if (refl) return launch_one<S, true, false>(*P, grid, lds_bytes, stream, e0, e1);              \
+        return launch_one<S, false, false>(*P, grid, lds_bytes, stream, e0, e1);                       \
     }
     RTC_CASE(SRC_SMEM)
     RTC_CASE(SRC_LDS1)

@@ -338,6 +338,28 @@ def test_empty_world_and_error_paths(rtc, gpu):
     assert e.value.status == 1
 
 
+def test_kernel_times_ring(rtc, scenes):
+    """rtc_kernel_times_ms: one (start, stop) event pair per render launch, newest `cap` kept,
+    oldest first; nothing launched yet -> empty / RTC_ERR_ARG from rtc_last_kernel_ms."""
+    ctx = rtc.Context(0)
+    assert len(ctx.kernel_times_ms()) == 0
+    with pytest.raises(rtc.RtcError):
+        ctx.last_kernel_ms()
+    w, cam = scenes.synthetic(20, 320, 200)
+    dw = ctx.upload(w)
+    for _ in range(5):
+        dw.render(cam)
+    t = ctx.kernel_times_ms()
+    assert len(t) == 5 and (t > 0).all() and (t < 50).all()
+    assert len(ctx.kernel_times_ms(3)) == 3 and ctx.kernel_times_ms(3)[-1] == t[-1] == np.float32(ctx.last_kernel_ms())
+    for _ in range(1030):   # wraps the 1024-pair ring
+        dw.render(cam)
+    t = ctx.kernel_times_ms(4096)
+    assert len(t) == 1024 and (t > 0).all()
+    dw.close()
+    ctx.close()
+
+
 # ------------------------------------------------------------------ BASELINE-size properties
 def test_full_size_north_star_scene(rtc, gpu, O, scenes):
     """1920x1080 x 100 spheres (+ floor): sampled pixels against the oracle, render vs render_async,

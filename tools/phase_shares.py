@@ -20,13 +20,15 @@ refl = len(sys.argv) > 2 and sys.argv[2] == "reflective"
 w, cam = scenes.synthetic(n, 1920, 1080, with_plane=(n <= 1000), reflective=refl)
 ctx = rtc.Context(0)
 dw = ctx.upload(w)
-buf = torch.zeros((1080, 1920, 3), dtype=torch.float64, device="cuda:0")
+y0, y1 = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (0, 1080)  # one rank's row tile
+buf = torch.zeros((y1 - y0, 1920, 3), dtype=torch.float64, device="cuda:0")
 torch.cuda.synchronize()
 for _ in range(3):
-    dw.render_rows(cam, 0, 1080, buf.data_ptr())
+    dw.render_rows(cam, y0, y1, buf.data_ptr())
 ctx.reset_stats()
-dw.render_rows(cam, 0, 1080, buf.data_ptr())
+dw.render_rows(cam, y0, y1, buf.data_ptr())
 ctx.synchronize()
+NW = 30 * ((y1 - y0 + 7) // 8) * 8  # waves launched: 8x8-pixel tiles, 32x8 blocks
 out = (C.c_ulonglong * 24)()
 rtc.lib().rtc_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
 rtc.lib().rtc_debug_counters(ctx._h, out, 24)
@@ -35,7 +37,7 @@ names = ["ray generation", "primary bundle", "primary cull + closest hit", "hit 
 tot = sum(out[8 + i] for i in range(7))
 print(f"objects {len(w)}  kernel_ms(stamped) {ctx.last_kernel_ms():.3f}  waves {out[0] // 64 if out[0] else 0}")
 for i, nm in enumerate(names):
-    print(f"  {nm:28s} {out[8 + i] / max(tot, 1) * 100:5.1f} %   {out[8 + i] / 32400:9.0f} ticks/wave")
+    print(f"  {nm:28s} {out[8 + i] / max(tot, 1) * 100:5.1f} %   {out[8 + i] / NW:9.0f} ticks/wave")
 d = [out[16 + i] for i in range(8)]
-print(f"per wave: closest passes {d[0] / 32400:.2f} (unbounded bundle {d[1] / 32400:.2f}), exact tests/closest pass {d[2] / max(d[0], 1):.2f}; "
-      f"shadow passes {d[3] / 32400:.2f} (unbounded {d[4] / 32400:.2f}), exact tests/shadow pass {d[5] / max(d[3], 1):.2f}")
+print(f"per wave: closest passes {d[0] / NW:.2f} (unbounded bundle {d[1] / NW:.2f}), exact tests/closest pass {d[2] / max(d[0], 1):.2f}; "
+      f"shadow passes {d[3] / NW:.2f} (unbounded {d[4] / NW:.2f}), exact tests/shadow pass {d[5] / max(d[3], 1):.2f}")
