@@ -259,6 +259,12 @@ rtc_status  rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_came
  * canvas into `rgb` (vsize*hsize*3 doubles). Synchronous. `stats` may be NULL. */
 rtc_status  rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,
                        uint32_t mode, uint32_t flags, double *rgb, rtc_stats *stats);
+/* Page-locked host memory for canvases handed to rtc_render: a canvas from rtc_host_alloc is
+ * filled by one DMA at link speed, ordinary (pageable) memory goes through the runtime's bounce
+ * buffers and is several times slower. What the reference would use for Canvas.pixels
+ * (canvas.rs:16-22) when it renders every frame through this library. [device] */
+rtc_status  rtc_host_alloc(size_t bytes, void **out);
+void        rtc_host_free(void *p);
 /* Ray counters accumulated since the last reset (synchronises the stream). */
 rtc_status  rtc_stats_read(rtc_context *ctx, rtc_stats *out);
 rtc_status  rtc_stats_reset(rtc_context *ctx);

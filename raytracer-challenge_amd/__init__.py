@@ -325,6 +325,31 @@ class Context:
         return out
 
 
+class _Pinned:
+    """Owner of one rtc_host_alloc block; freed when the last array viewing it is gone."""
+
+    def __init__(self, nbytes: int):
+        self.ptr = C.c_void_p()
+        _check(lib().rtc_host_alloc(nbytes, C.byref(self.ptr)), "rtc_host_alloc")
+        self.buf = (C.c_char * nbytes).from_address(self.ptr.value)
+        self.buf._owner = self  # numpy views hold `buf`; the cycle keeps this owner exactly as long
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                lib().rtc_host_free(self.ptr)
+                self.ptr = C.c_void_p()
+        except Exception:
+            pass
+
+
+def host_canvas(vsize: int, hsize: int) -> np.ndarray:
+    """A zeroed (vsize, hsize, 3) float64 canvas in page-locked memory (rtc_host_alloc)."""
+    arr = np.frombuffer(_Pinned(vsize * hsize * 24).buf, dtype=np.float64).reshape(vsize, hsize, 3)
+    arr[...] = 0.0
+    return arr
+
+
 class DeviceWorld:
     """Flattened World resident in HBM (rtc_world)."""
 
@@ -347,9 +372,14 @@ class DeviceWorld:
         except Exception:
             pass
 
-    def render(self, cam: RtcCamera, mode: int = MODE_RENDER_ASYNC, flags: int = 0, with_stats: bool = False):
-        """Camera::render(&World) -> Canvas as a (vsize, hsize, 3) float64 array (host)."""
-        out = np.empty((cam.vsize, cam.hsize, 3), dtype=np.float64)
+    def render(self, cam: RtcCamera, mode: int = MODE_RENDER_ASYNC, flags: int = 0, with_stats: bool = False,
+               out: np.ndarray | None = None):
+        """Camera::render(&World) -> Canvas as a (vsize, hsize, 3) float64 array (host). `out` = a
+        canvas to reuse, e.g. one from host_canvas() (page-locked: the copy runs at link speed)."""
+        if out is None:
+            out = np.empty((cam.vsize, cam.hsize, 3), dtype=np.float64)
+        elif out.shape != (cam.vsize, cam.hsize, 3) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous (vsize, hsize, 3) float64 array")
         st = RtcStats()
         _check(lib().rtc_render(self.ctx._h, self._h, C.byref(cam), mode, flags, out.ctypes.data_as(C.POINTER(C.c_double)),
                                 C.byref(st) if with_stats else None), "rtc_render")

@@ -90,6 +90,8 @@ PROTOTYPES = {
     "rtc_world_destroy": (None, [VP]),
     "rtc_render_rows": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, U32, VP, VP, U32]),
     "rtc_render": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, PD, C.POINTER(RtcStats)]),
+    "rtc_host_alloc": (C.c_int32, [C.c_size_t, C.POINTER(VP)]),
+    "rtc_host_free": (None, [VP]),
     "rtc_stats_read": (C.c_int32, [VP, C.POINTER(RtcStats)]),
     "rtc_stats_reset": (C.c_int32, [VP]),
     "rtc_kernel_times_ms": (C.c_int32, [VP, C.POINTER(C.c_float), U32, C.POINTER(U32)]),

@@ -32,6 +32,9 @@ struct rtc_context {
     static constexpr uint32_t EV_RING = 1024;
     hipEvent_t ev[EV_RING][2] = {};
     uint64_t launches = 0;
+    // device canvas of rtc_render (host-canvas entry point): grow-only, reused between frames
+    double *d_canvas = nullptr;
+    size_t canvas_bytes = 0;
     int force_src = -1;   // RTC_SRC env override (experiments)
     uint32_t tile_cap = 512;
 };
@@ -280,6 +283,7 @@ void rtc_context_destroy(rtc_context *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    if (ctx->d_canvas) (void)hipFree(ctx->d_canvas);
     for (auto &pair : ctx->ev)
         for (hipEvent_t e : pair)
             if (e) (void)hipEventDestroy(e);
@@ -585,16 +589,38 @@ rtc_status rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *ca
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t bytes = sizeof(double) * 3 * (size_t)cam->hsize * cam->vsize;
     if (bytes == 0) return RTC_ERR_ARG;
-    double *d = nullptr;
-    HIP_TRY(hipMalloc(&d, bytes));
+    if (ctx->canvas_bytes < bytes) { // grow-only scratch canvas: no hipMalloc/hipFree (a device sync) per frame
+        if (ctx->d_canvas) (void)hipFree(ctx->d_canvas);
+        ctx->d_canvas = nullptr;
+        ctx->canvas_bytes = 0;
+        HIP_TRY(hipMalloc(&ctx->d_canvas, bytes));
+        ctx->canvas_bytes = bytes;
+    }
+    double *d = ctx->d_canvas;
     rtc_status st = RTC_OK;
     if (stats) st = rtc_stats_reset(ctx);
     if (st == RTC_OK) st = rtc_render_rows(ctx, w, cam, mode, 0, cam->vsize, d, nullptr, flags);
+    // `rgb` from rtc_host_alloc (page-locked) is filled by one DMA at link speed; pageable memory
+    // goes through the runtime's bounce buffers (several times slower)
     if (st == RTC_OK && hipMemcpyAsync(rgb, d, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
     if (st == RTC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
     if (st == RTC_OK && stats) st = rtc_stats_read(ctx, stats);
-    (void)hipFree(d);
     return st;
+}
+
+rtc_status rtc_host_alloc(size_t bytes, void **out) {
+    if (!out || bytes == 0) return RTC_ERR_ARG;
+    *out = nullptr;
+    void *p = nullptr;
+    const hipError_t e = hipHostMalloc(&p, bytes, hipHostMallocDefault);
+    if (e == hipErrorOutOfMemory) return RTC_ERR_NOMEM;
+    if (e != hipSuccess) return RTC_ERR_DEVICE;
+    *out = p;
+    return RTC_OK;
+}
+
+void rtc_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
 }
 
 rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays, uint32_t n, uint32_t remaining,

@@ -121,6 +121,34 @@ def test_reference_kats_through_color_at(rtc, gpu, O):
         assert feq(gpu.upload(w).color_at(ray, 5)[0], want)
 
 
+def test_reference_jd_and_smoke_tests_on_gpu(rtc, gpu, O):
+    """shape.rs:1114-1130 (color_at_jd1: grazing ray, not black), shape.rs:867-882 (intersect_jd1),
+    camera.rs:233-247 (render_jd1, 101x101 `render`), camera.rs:250-254 (async1, default World
+    20x10 `render_async`): HIP path == oracle (colours to TIGHT_TOL: pow is not bit-exact)."""
+    n = math.sin(math.pi * 3.0 / 4.0)
+    d = 1.0 / math.sqrt(2.0)
+    ray = np.array([[0, 0, -2.0 * n, 0, d, d]])
+    for scale in (1.00001, 1.0):
+        w = rtc.World()
+        w.add_shape(rtc.sphere(rtc.Matrix.identity().scaling(scale, scale, scale), rtc.material(color=(1, 0, 0))))
+        rgb, hits = gpu.upload(w).color_at(ray, 1, want_hits=True)
+        want = O.color_at(w.array(), 1, w.light, tuple(ray[0]), 1)
+        assert np.max(np.abs(rgb[0] - np.array(want))) <= TIGHT_TOL and bool(rgb[0].any()) == bool(np.any(want))
+        if scale != 1.0:
+            assert rgb[0].any() and hits[0].hit_index == 0
+    w = rtc.World()
+    w.add_shape(rtc.sphere(rtc.Matrix.identity().scaling(2, 2, 2).translation(0, 1.01, 0)))
+    cam = rtc.camera(101, 101, math.pi / 2, rtc.Matrix.make_view_transform((0, 0, -5), (0, 0, 0), (0, 1, 0)))
+    got = gpu.upload(w).render(cam, rtc.MODE_RENDER)
+    want = O.render(w.array(), 1, w.light, cam, mode=0)
+    assert np.max(np.abs(got - want)) <= TIGHT_TOL and np.array_equal(got != 0, want != 0) and got[50, 50].any()
+    w = rtc.World.default()
+    cam = rtc.camera(20, 10, 1.5)
+    got = gpu.upload(w).render(cam, rtc.MODE_RENDER_ASYNC)
+    want = O.render(w.array(), 2, w.light, cam, mode=1)
+    assert np.max(np.abs(got - want)) <= TIGHT_TOL and np.array_equal(got != 0, want != 0) and got.any()
+
+
 def test_reflect5_n1_n2_on_gpu(rtc, gpu):
     """shape.rs:1268-1304: n1/n2 at each of the six intersections, exact; each intersection is made
     the ray's first hit by starting the ray just before it (earlier entries become negative t)."""
@@ -336,6 +364,26 @@ def test_empty_world_and_error_paths(rtc, gpu):
     with pytest.raises(rtc.RtcError) as e:
         rtc.sphere(rtc.Matrix.identity().scaling(0.001, 0.001, 0.001))
     assert e.value.status == 1
+
+
+def test_pinned_host_canvas(rtc, gpu, scenes):
+    """rtc_host_alloc canvases: same pixels as the pageable path, reusable between frames, freed
+    with the last view."""
+    import gc
+    w, cam = scenes.synthetic(20, 160, 90)
+    dw = gpu.upload(w)
+    want = dw.render(cam)
+    canvas = rtc.host_canvas(90, 160)
+    assert not canvas.any()
+    got = dw.render(cam, out=canvas)
+    assert got is canvas and np.array_equal(canvas, want)
+    view = canvas[10:20]
+    del canvas, got
+    gc.collect()
+    assert np.array_equal(view, want[10:20])   # the block lives as long as any view of it
+    with pytest.raises(ValueError):
+        dw.render(cam, out=np.zeros((90, 160, 4)))
+    dw.close()
 
 
 def test_kernel_times_ring(rtc, scenes):

@@ -279,6 +279,30 @@ def test_color_at1_2_3(O):
     assert veq(O.color_at(arr, 2, O.light(), (0, 0, 0.75, 0, 0, -1), 1), (1, 1, 1))
 
 
+def test_color_at_jd1_and_intersect_jd1(O):
+    """shape.rs:1114-1130 (grazing ray on a sphere scaled by 1.00001: colour must not be black) and
+    shape.rs:867-882 (the same ray against the unit sphere; the reference only prints the count)."""
+    n = math.sin(PI * 3.0 / 4.0)
+    d = 1.0 / math.sqrt(2.0)
+    ray = (0, 0, -2.0 * n, 0, d, d)
+    s = O.shape(0, O.chain(("scaling", 1.00001, 1.00001, 1.00001)), O.material(color=(1, 0, 0)))
+    c = O.color_at(O.world([s]), 1, O.light(), ray, 1)
+    assert tuple(c) != (0.0, 0.0, 0.0)
+    assert len(isect(O, s, ray)) == 2
+    assert len(isect(O, O.shape(0, O.chain(("scaling", 1.0, 1.0, 1.0))), ray)) in (0, 2)
+
+
+def test_render_jd1_and_async1(O):
+    """camera.rs:233-247 (101x101 render of a scaled, lifted sphere; the reference prints pixel
+    (50, 50)) and camera.rs:250-254 (render_async of the default World, 20x10: runs, every pixel)."""
+    s = O.shape(0, O.chain(("scaling", 2.0, 2.0, 2.0), ("translation", 0.0, 1.01, 0.0)))
+    cam = O.camera(101, 101, PI / 2, O.view_transform((0, 0, -5), (0, 0, 0), (0, 1, 0)))
+    img = O.render(O.world([s]), 1, O.light(), cam, mode=0)
+    assert img.shape == (101, 101, 3) and img[50, 50].any() and not img[100].any() and not img[:, 100].any()
+    img = O.render(O.world(O.default_world()), 2, O.light(), O.camera(20, 10, 1.5), mode=1)
+    assert img.shape == (10, 20, 3) and img.any()
+
+
 def test_shadow1(O):
     """shape.rs:1132-1144: exact (0.1, 0.1, 0.1)."""
     arr = O.world([O.shape(0), O.shape(0, O.chain(("translation", 0, 0, 10)))])

@@ -23,4 +23,13 @@ for _ in range(n):
     img, st = dw.render(cam, with_stats=True)
 dt = (time.perf_counter() - t) / n
 rays = st["rays_primary"] + st["rays_shadow"]
-print(f"rtc_render (host canvas) {dt * 1e3:.3f} ms/frame -> {rays / dt / 1e6:.0f} Mrays/s; canvas {img.nbytes / 1e6:.1f} MB -> {img.nbytes / dt / 1e9:.1f} GB/s effective")
+print(f"rtc_render (pageable host canvas) {dt * 1e3:.3f} ms/frame -> {rays / dt / 1e6:.0f} Mrays/s; canvas {img.nbytes / 1e6:.1f} MB -> {img.nbytes / dt / 1e9:.1f} GB/s effective")
+pinned = rtc.host_canvas(cam.vsize, cam.hsize)
+for _ in range(3):
+    dw.render(cam, out=pinned)
+t = time.perf_counter()
+for _ in range(n):
+    dw.render(cam, out=pinned)
+dt = (time.perf_counter() - t) / n
+assert (pinned == img).all()
+print(f"rtc_render (rtc_host_alloc canvas) {dt * 1e3:.3f} ms/frame -> {rays / dt / 1e6:.0f} Mrays/s; {img.nbytes / dt / 1e9:.1f} GB/s effective")
