@@ -332,6 +332,7 @@ DEVI bool finite3(V3 v) { return fabs(v.x) < __builtin_inf() && fabs(v.y) < __bu
 // deviation from it.
 template <bool SHARED, bool REACH>
 DEVI Bundle make_bundle(bool active, V3 apex, V3 o, V3 d, double reach) {
+#pragma clang fp contract(fast) // cull arithmetic (see bundle_touches)
     Bundle B;
     float fx = 0.f, fy = 0.f, fz = 0.f;
     bool good = active && finite3(o) && finite3(d);
@@ -417,6 +418,9 @@ DEVI Bundle make_bundle(bool active, V3 apex, V3 o, V3 d, double reach) {
 // touch the solid cone only if that is <= Re, it is not wholly behind the apex plane, and it
 // is within reach. Squares instead of square roots.
 DEVI bool bundle_touches(const Bundle &B, const DevBound &b) {
+#pragma clang fp contract(fast) // cull arithmetic, not reference arithmetic: the file is compiled with
+                                // -ffp-contract=off for the exact tests; here FMA halves the dot products and only
+                                // tightens the rounding that the slacks below already cover
     if (B.off) return true;
     if (!(b.r < __builtin_inf())) return true;
     const double wx = b.cx - B.px, wy = b.cy - B.py, wz = b.cz - B.pz;
@@ -447,6 +451,7 @@ DEVI bool bundle_touches(const Bundle &B, const DevBound &b) {
 // then issued only if some lane of the wave passes. (For coherent primary / shadow bundles the
 // wave-level cull already leaves 1-2 candidates per pass and this filter would only add work.)
 DEVI bool ray_touches(V3 o, V3 d, const DevBound &b) {
+#pragma clang fp contract(fast) // cull arithmetic, not reference arithmetic: FMA only tightens the rounding the slacks cover
     if (!(b.r < __builtin_inf())) return true;
     const double wx = b.cx - o.x, wy = b.cy - o.y, wz = b.cz - o.z;
     const double Dub = fabs(wx) + fabs(wy) + fabs(wz); // >= |C - o|
@@ -685,7 +690,13 @@ DEVI ParamPtr param_view() {
 }
 #define KP(arg) (*param_view())
 
-struct Frame {
+// One suspended shade_hit call (shape.rs:685-700) on a lane's stack. The stack lives in scratch
+// (dynamic index), so its size is HBM/L2 traffic: Worlds without transparent materials (REFR ==
+// false) recurse along a single chain `surface + color_at(reflected ray) * kr` and need only
+// (surface, kr) = 32 bytes per level instead of 152 (1080p reflective north star: 1.67 GB of
+// scratch writes per frame with the full frame).
+template <bool REFR> struct FrameT;
+template <> struct FrameT<true> {
     V3 surface;
     V3 reflected;
     V3 ro, rd;      // pending refraction ray
@@ -694,6 +705,10 @@ struct Frame {
     uint8_t state;  // 0 waiting for the reflected child, 1 waiting for the refracted child
     uint8_t schlick;
     uint8_t has_refr;
+};
+template <> struct FrameT<false> {
+    V3 surface;
+    double kr;
 };
 
 // Color::scale(component, 255) color.rs:100-114: `(c * 255.0) as i32` (truncating, saturating,
@@ -774,6 +789,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     const uint32_t nsamples = (probe || P.samples == 1u) ? 1u : 4u;
     V3 result = mk(0., 0., 0.);
 
+    typedef FrameT<REFR> Frame;
     Frame stack[REFL ? RTC_MAX_STACK : 1];
 
     for (uint32_t s = 0; s < nsamples; ++s) {
@@ -1028,7 +1044,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     val = combine(surface, mk(0., 0., 0.), mk(0., 0., 0.), schlick, R);
                     have_val = true;
                 } else {
-                    if constexpr (REFL) {
+                    if constexpr (REFR) {
                         Frame &F = stack[sp];
                         F.surface = surface;
                         F.reflected = mk(0., 0., 0.);
@@ -1042,6 +1058,13 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                         if (want_refl) { ro = over; rd = reflectv; l_refl = true; } // Ray::new(over_point, reflectv) shape.rs:734
                         else { ro = fr_o; rd = fr_d; l_refr = true; }               // Ray::new(under_point, direction) shape.rs:764
                         rem = rem - 1;
+                    } else if constexpr (REFL) { // reflection only: want_refl holds here
+                        Frame &F = stack[sp];
+                        F.surface = surface;
+                        F.kr = m_kr;
+                        ++sp;
+                        ro = over; rd = reflectv; l_refl = true;                     // shape.rs:734
+                        rem = rem - 1;
                     }
                 }
             }
@@ -1050,7 +1073,14 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             // ---- return `val` to the callers (unwind) ------------------------------------------
             if (have_val) {
                 bool relaunched = false;
-                if constexpr (REFL) {
+                if constexpr (REFL && !REFR) {
+                    while (sp > 0) { // surface + reflected + refracted(BLACK), innermost call first shape.rs:692-699
+                        const Frame &F = stack[sp - 1];
+                        val = combine(F.surface, vmul(val, F.kr), mk(0., 0., 0.), false, 0.);
+                        --sp;
+                    }
+                }
+                if constexpr (REFR) {
                     while (sp > 0) {
                         Frame &F = stack[sp - 1];
                         if (F.state == 0) {
