@@ -58,7 +58,7 @@ for k in range(n_worlds):
         bad += 1
         print(f"MISMATCH seed {seed} objects {len(w)} max|d|={np.max(np.abs(got - brute)):.3e} stats {st} vs {sb}", flush=True)
     dw.close()
-    if k % 5000 == 4999:
+    if k % 2000 == 1999:
         print(f"{k + 1} worlds, {bad} mismatches, {time.time() - t0:.0f}s", flush=True)
 print(f"done: {n_worlds} worlds, {bad} mismatches")
 sys.exit(1 if bad else 0)
