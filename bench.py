@@ -281,12 +281,14 @@ def cpu_baseline(world, cam, budget_s):
     dt = max(1e-6, time.perf_counter() - t)
     est_frame = dt * H / band
     if est_frame <= budget_s:
-        frames = max(1, int(budget_s / est_frame))
         t = time.perf_counter()
-        rays = 0
-        for _ in range(frames):
+        rays = frames = 0
+        while frames == 0 or (time.perf_counter() - t) + est_frame <= budget_s:   # whole frames until the budget is used
+            t1 = time.perf_counter()
             _, st = O.render(arr, len(world), world.light, cam, mode=1, nthreads=cores, want_stats=True)
+            est_frame = time.perf_counter() - t1
             rays += st["rays_primary"] + st["rays_shadow"]
+            frames += 1
         dt = time.perf_counter() - t
         sample = f"{frames} full frame(s) {cam.hsize}x{cam.vsize}"
     else:

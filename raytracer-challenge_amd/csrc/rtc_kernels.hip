@@ -28,6 +28,16 @@
 
 #define RTC_BLOCK 256
 #define RTC_MAX_STACK 8
+#ifndef RTC_TILE_ORDER
+// Workgroup id -> tile. The hardware deals consecutive workgroup ids round-robin over the 8 XCDs.
+// 1 (default): tile = workgroup id, so every XCD gets every 8th tile of the image — an even share
+//    of sky, floor and spheres. 0: remap so that each XCD owns one contiguous band of rows (the
+//    usual "XCD-aware" advice, for L2 locality): here there is nothing to share (the scene is 50 KB,
+//    the canvas is write-once) and the bands are wildly uneven (sky above, everything below), so
+//    the top XCDs idle: north star 0.099 ms vs 0.073 ms, reflective 1.07 vs 0.69 ms, 10 000
+//    spheres 0.66 vs 0.54 ms. 2: round-robin, bottom rows first (no better than 1).
+#define RTC_TILE_ORDER 1
+#endif
 // 2nd argument of __launch_bounds__ = minimum waves per SIMD (caps VGPRs: 5 -> 96, 4 -> 128,
 // 3 -> 168, 2 -> 256). Measured on the north-star scene (culled flat kernel, built with
 // -disable-machine-licm, 112 VGPRs uncapped): 4 -> 0.120 ms, 5 -> 0.113 ms, 6 -> 0.121 ms.
@@ -748,13 +758,16 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     const uint32_t wave = threadIdx.x >> 6;
     constexpr bool probe = PROBE;
 
-    // XCD-aware remap: hardware deals consecutive workgroup ids round-robin over the 8 XCDs;
-    // give each XCD a contiguous run of logical tiles (bijective for any grid size).
+    // workgroup id -> tile: see RTC_TILE_ORDER (XCD balance beats XCD locality here)
     uint32_t bid = blockIdx.x;
+#if RTC_TILE_ORDER == 0
     {
         const uint32_t nb = gridDim.x, q = nb / 8u, r = nb % 8u, xcd = bid % 8u, k = bid / 8u;
         bid = (xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q) + k;
     }
+#elif RTC_TILE_ORDER == 2
+    bid = gridDim.x - 1u - bid;
+#endif
 
     uint32_t px = 0, py = 0, ray_index = 0;
     bool in_range, traced;
