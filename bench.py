@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--gather", default="u8", choices=["u8", "f64"],
                     help="what rank 0 collects: the 8-bit frame (Color::scale, 3 B/pixel - what every file writer of the "
                          "reference consumes) or the raw f64 canvas (24 B/pixel; xGMI-ingest bound at this frame size)")
+    ap.add_argument("--tiling", default="bands", choices=["bands", "rows"],
+                    help="how the rows are cut across ranks: 8-row bands dealt round-robin (even work per rank; rank 0 "
+                         "un-deals them after the gather) or one contiguous range of rows per rank")
     return ap.parse_args()
 
 
@@ -129,8 +132,10 @@ def main():
 
     W, H = args.width, args.height
     world, cam = scenes.synthetic(args.spheres, W, H, with_plane=not args.no_plane, reflective=args.reflective)
+    banded = args.tiling == "bands" and (world_size > 1 or args.force_dist)
     y0, y1 = tiles.row_range(H, world_size, rank)
-    rows_max = tiles.rows_per_rank(H, world_size)
+    rows_max = tiles.packed_rows(H, world_size) if banded else tiles.rows_per_rank(H, world_size)
+    rows_mine = (sum(min(8, H - 8 * b) for b in tiles.bands_of_rank(H, world_size, rank)) if banded else y1 - y0)
 
     # launch on torch's current stream so that torch events and RCCL order against the kernels
     stream = torch.cuda.current_stream(dev)
@@ -148,6 +153,11 @@ def main():
     canvases = [torch.empty((world_size * rows_max, W, 3), dtype=gdtype, device=gdev) for _ in range(nbuf)] \
         if (rank == 0 and dist_on) else [None] * nbuf
     bands = [tiles.band_views(c, world_size) if c is not None else None for c in canvases]
+    # interleaved bands: the gather delivers rank-major bands; rank 0 un-deals them into image order
+    frames = [torch.empty_like(c) for c in canvases] if (banded and rank == 0) else None
+    undeal = [tiles.deinterleave_views(c, f, world_size) for c, f in zip(canvases, frames)] if frames is not None else None
+    # (the un-deal copy stays on the launch stream: a side stream would hide its ~8 us of GPU time but costs
+    # more than that in host calls per frame, and at this frame size rank 0 is host-bound)
     pending = [None] * nbuf
     state = {"k": 0}
 
@@ -155,22 +165,31 @@ def main():
         b = state["k"] % nbuf
         state["k"] += 1
         if pending[b] is not None:
-            pending[b].wait()       # current stream waits for the gather that last used buffer b
-            pending[b] = None
+            finish(b)               # current stream waits for the gather that last used buffer b
         tile, tile8 = tile_bufs[b], tile8_bufs[b]
-        dworld.render_rows(cam, y0, y1, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
+        if banded:
+            dworld.render_bands(cam, rank, world_size, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
+        else:
+            dworld.render_rows(cam, y0, y1, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
         if dist_on:
             src = tile8 if args.gather == "u8" else tile
             src = src.cpu() if gloo else src
             work = tiles.gather_tiles(src, canvases[b], world_size, rank, async_op=not args.no_overlap, bands=bands[b])
             if work is not None:
                 pending[b] = work
+            elif frames is not None:
+                undeal[b][0].copy_(undeal[b][1])
+
+    def finish(b):
+        work, pending[b] = pending[b], None
+        work.wait()                 # the launch stream waits for the gather (its tile buffer is rendered into next)
+        if frames is not None:      # rank 0: bands back into image order (one strided device copy)
+            undeal[b][0].copy_(undeal[b][1])
 
     def drain():
         for b in range(nbuf):
             if pending[b] is not None:
-                pending[b].wait()
-                pending[b] = None
+                finish(b)
 
     for _ in range(args.warmup):
         step()
@@ -209,7 +228,7 @@ def main():
     if rank == 0:
         steps = max(1, args.steps)
         value = rays_ps / elapsed / 1e6
-        rows = y1 - y0
+        rows = rows_mine
         abytes = algorithmic_bytes(W, rows, world)
         rays_rank = (st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"] + st["rays_refract"]) / steps
         hits_rank = st["rays_shadow"] / steps  # one shadow ray per shaded hit (shape.rs:688)
@@ -232,7 +251,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": workload,
-                "objects": len(world), "rows_per_gpu": rows, "parallelism": (f"row-tiles x{world_size} + {'gloo (rehearsal)' if gloo else 'RCCL'} gather of the "
+                "objects": len(world), "rows_per_gpu": rows, "parallelism": (f"{'8-row bands dealt round-robin' if banded else 'contiguous row tiles'} x{world_size} + {'gloo (rehearsal)' if gloo else 'RCCL'} gather of the "
                                                                           f"{'8-bit frame (Color::scale)' if args.gather == 'u8' else 'f64 canvas'} to rank 0"
                                                                           + ("" if args.no_overlap else ", gather k overlapped with render k+1")) if dist_on else "single GPU",
                 "exchange_bytes_per_frame": (W * H * (3 if args.gather == "u8" else 24) * (world_size - 1) // world_size) if dist_on else 0,

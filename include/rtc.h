@@ -255,6 +255,18 @@ void        rtc_world_destroy(rtc_world *w);
 rtc_status  rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,
                             uint32_t mode, uint32_t y0, uint32_t y1, void *d_rgb, void *d_rgb8,
                             uint32_t flags);
+/* Interleaved row tiles (multi-GPU load balance). The canvas is cut into bands of RTC_BAND_ROWS
+ * rows (band b = rows [8b, 8b+8) of the image, the last one possibly short); this call renders
+ * bands first_band, first_band + band_stride, first_band + 2*band_stride, ... and packs them one
+ * after the other into d_rgb / d_rgb8 (the k-th band of this call at rows [8k, 8k+8) of the
+ * buffer; buffers hold ceil((nbands - first_band) / band_stride) * 8 rows). With one process per
+ * GPU, rank r of N calls (first_band = r, band_stride = N): every rank gets an even share of sky,
+ * floor and objects, where contiguous ranges of rows (rtc_render_rows) leave the ranks with the
+ * sky idle. Same per-pixel contract as rtc_render_rows (camera.rs:151-156). [device] */
+#define RTC_BAND_ROWS 8u
+rtc_status  rtc_render_bands(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,
+                             uint32_t mode, uint32_t first_band, uint32_t band_stride,
+                             void *d_rgb, void *d_rgb8, uint32_t flags);
 /* Camera::render(&World) -> Canvas with host memory: renders all rows and copies the
  * canvas into `rgb` (vsize*hsize*3 doubles). Synchronous. `stats` may be NULL. */
 rtc_status  rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,

@@ -395,6 +395,13 @@ class DeviceWorld:
         _check(lib().rtc_render_rows(self.ctx._h, self._h, C.byref(cam), mode, y0, y1, C.c_void_p(d_ptr),
                                      C.c_void_p(d_ptr8 or None), flags), "rtc_render_rows")
 
+    def render_bands(self, cam: RtcCamera, first_band: int, band_stride: int, d_ptr: int, mode: int = MODE_RENDER_ASYNC,
+                     flags: int = 0, d_ptr8: int | None = None) -> None:
+        """Enqueue the 8-row bands first_band, first_band + band_stride, ... packed one after the
+        other into the DEVICE buffer at `d_ptr` (interleaved row tiles, include/rtc.h)."""
+        _check(lib().rtc_render_bands(self.ctx._h, self._h, C.byref(cam), mode, first_band, band_stride, C.c_void_p(d_ptr),
+                                      C.c_void_p(d_ptr8 or None), flags), "rtc_render_bands")
+
     def color_at(self, rays: np.ndarray, remaining: int = 5, want_hits: bool = False, flags: int = 0):
         """World::color_at for an (n, 6) array of rays; returns rgb (n,3) [and the rtc_hit array]."""
         r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)

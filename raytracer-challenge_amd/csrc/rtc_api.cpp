@@ -485,12 +485,11 @@ void rtc_world_destroy(rtc_world *w) {
     delete w;
 }
 
-rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode, uint32_t y0,
-                           uint32_t y1, void *d_rgb, void *d_rgb8, uint32_t flags) {
-    if (!ctx || !w || !cam || !d_rgb || w->ctx != ctx) return RTC_ERR_ARG;
-    if (mode > RTC_MODE_RENDER_ASYNC || cam->hsize == 0 || cam->vsize == 0 || y0 > y1 || y1 > cam->vsize) return RTC_ERR_ARG;
+// rows [y0, y1) in tile rows of 8, tile row k at image rows y0 + 8*k*band_stride; grid_y tile rows
+static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode, uint32_t y0,
+                                uint32_t y1, uint32_t band_stride, uint32_t grid_y, void *d_rgb, void *d_rgb8,
+                                uint32_t flags) {
     HIP_TRY(hipSetDevice(ctx->device));
-    if (y0 == y1) return RTC_OK;
     RenderParams P;
     std::memset(&P, 0, sizeof P);
     fill_world(P, w);
@@ -504,7 +503,8 @@ rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camer
     P.rays = nullptr;
     P.remaining = RTC_MAX_REFLECTIONS; // render_pixel passes Camera::MAX_REFLECTIONS camera.rs:98
     P.grid_x = (cam->hsize + 31u) / 32u;
-    P.grid_y = (y1 - y0 + 7u) / 8u;
+    P.grid_y = grid_y;
+    P.band_stride = band_stride;
     int src;
     size_t lds_bytes;
     choose_source(ctx, w->n, flags, &src, &P.tile_cap, &lds_bytes);
@@ -518,6 +518,24 @@ rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camer
                              pair[0], pair[1]));
     ++ctx->launches;
     return RTC_OK;
+}
+
+rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode, uint32_t y0,
+                           uint32_t y1, void *d_rgb, void *d_rgb8, uint32_t flags) {
+    if (!ctx || !w || !cam || !d_rgb || w->ctx != ctx) return RTC_ERR_ARG;
+    if (mode > RTC_MODE_RENDER_ASYNC || cam->hsize == 0 || cam->vsize == 0 || y0 > y1 || y1 > cam->vsize) return RTC_ERR_ARG;
+    if (y0 == y1) return RTC_OK;
+    return render_launch(ctx, w, cam, mode, y0, y1, 1u, (y1 - y0 + 7u) / 8u, d_rgb, d_rgb8, flags);
+}
+
+rtc_status rtc_render_bands(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode,
+                            uint32_t first_band, uint32_t band_stride, void *d_rgb, void *d_rgb8, uint32_t flags) {
+    if (!ctx || !w || !cam || !d_rgb || w->ctx != ctx) return RTC_ERR_ARG;
+    if (mode > RTC_MODE_RENDER_ASYNC || cam->hsize == 0 || cam->vsize == 0 || band_stride == 0) return RTC_ERR_ARG;
+    const uint32_t nbands = (cam->vsize + RTC_BAND_ROWS - 1u) / RTC_BAND_ROWS;
+    if (first_band >= nbands) return RTC_OK; // this caller owns no band of so small a canvas
+    const uint32_t mine = (nbands - first_band + band_stride - 1u) / band_stride;
+    return render_launch(ctx, w, cam, mode, first_band * RTC_BAND_ROWS, cam->vsize, band_stride, mine, d_rgb, d_rgb8, flags);
 }
 
 rtc_status rtc_stats_read(rtc_context *ctx, rtc_stats *out) {
@@ -650,6 +668,7 @@ rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays
         P.hits = d_hits;
         P.grid_x = (n + 255u) / 256u;
         P.grid_y = 1;
+        P.band_stride = 1;
         int src;
         size_t lds_bytes;
         choose_source(ctx, w->n, flags, &src, &P.tile_cap, &lds_bytes);

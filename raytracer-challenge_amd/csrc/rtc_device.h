@@ -85,15 +85,18 @@ struct RenderParams {
     uint32_t W, H, y0, y1, mode, samples;
     double half_width, half_height, pixel_size;
     double vinv[12];
-    double *out;                 // (y1-y0) x W x 3
+    double *out;                 // rows x W x 3, rows = y1-y0 (band_stride 1) or 8*grid_y (packed bands)
     unsigned char *out8;         // optional: the same rows quantised by Color::scale(c, 255)
     unsigned long long *counters; // CNT_N
     // probe mode (rtc_color_at): rays != nullptr
     const double *rays;
     uint32_t nrays, remaining;
     void *hits; // rtc_hit[nrays] or nullptr
-    uint32_t grid_x, grid_y; // logical block grid of the render (for the XCD-aware remap)
+    uint32_t grid_x, grid_y; // logical block grid of the render
     uint32_t flags;          // RTC_FLAG_*
+    uint32_t band_stride;    // tile row k of the grid renders image rows y0 + 8*k*band_stride .. (+8) and
+                             // writes output rows 8*k .. (+8): 1 = a contiguous range of rows, N = every
+                             // N-th band of 8 rows (interleaved row tiles, rtc_render_bands)
 };
 
 #endif

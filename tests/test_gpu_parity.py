@@ -366,6 +366,38 @@ def test_empty_world_and_error_paths(rtc, gpu):
     assert e.value.status == 1
 
 
+@pytest.mark.parametrize("H", [90, 93, 5])
+def test_interleaved_bands_compose_the_frame(rtc, gpu, scenes, H):
+    """rtc_render_bands: for N = 1, 2, 3, 8 the packed bands of all `ranks`, un-dealt with
+    tiles.deinterleave, are the full frame bit for bit (f64 and 8-bit), and the ray counts add up."""
+    import torch
+    tiles = importlib.import_module(rtc.__name__ + ".tiles")
+    w, cam = scenes.synthetic(25, 160, H)
+    dw = gpu.upload(w)
+    full, st_full = dw.render(cam, rtc.MODE_RENDER_ASYNC, with_stats=True)
+    full8 = rtc.color_scale255(full).reshape(full.shape)
+    for N in (1, 2, 3, 8):
+        per = tiles.packed_rows(H, N)
+        gathered = torch.full((N * per, 160, 3), -1.0, dtype=torch.float64, device="cuda:0")
+        gathered8 = torch.full((N * per, 160, 3), 77, dtype=torch.uint8, device="cuda:0")
+        gpu.reset_stats()
+        for r in range(N):
+            dw.render_bands(cam, r, N, gathered[r * per:].data_ptr(), d_ptr8=gathered8[r * per:].data_ptr())
+        st = gpu.stats()
+        assert st == st_full, (N, st, st_full)
+        canvas = tiles.deinterleave(gathered, torch.empty_like(gathered), N)
+        canvas8 = tiles.deinterleave(gathered8, torch.empty_like(gathered8), N)
+        assert np.array_equal(canvas[:H].cpu().numpy(), full), N
+        assert np.array_equal(canvas8[:H].cpu().numpy(), full8), N
+        # slots beyond the bands a rank owns are never written
+        for r in range(N):
+            used = 8 * len(tiles.bands_of_rank(H, N, r))
+            assert (gathered[r * per + used:(r + 1) * per] == -1.0).all()
+    with pytest.raises(rtc.RtcError):
+        dw.render_bands(cam, 0, 0, gathered.data_ptr())
+    dw.close()
+
+
 def test_pinned_host_canvas(rtc, gpu, scenes):
     """rtc_host_alloc canvases: same pixels as the pageable path, reusable between frames, freed
     with the last view."""
