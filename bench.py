@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--gather", default="u8", choices=["u8", "f64"],
                     help="what rank 0 collects: the 8-bit frame (Color::scale, 3 B/pixel - what every file writer of the "
                          "reference consumes) or the raw f64 canvas (24 B/pixel; xGMI-ingest bound at this frame size)")
+    ap.add_argument("--frames-per-exchange", type=int, default=8,
+                    help="N>1: how many frames' tiles each rank sends per RCCL gather (1 = a gather per frame)")
     ap.add_argument("--tiling", default="bands", choices=["bands", "rows"],
                     help="how the rows are cut across ranks: 8-row bands dealt round-robin (even work per rank; rank 0 "
                          "un-deals them after the gather) or one contiguous range of rows per rank")
@@ -141,52 +143,74 @@ def main():
     stream = torch.cuda.current_stream(dev)
     ctx = rtc.Context(dev_index, stream=stream.cuda_stream)
     dworld = ctx.upload(world)
-    # two tile / canvas buffers: the RCCL gather of frame k runs (on RCCL's own stream) while frame
-    # k+1 renders; a buffer is reused only after the gather that reads or fills it has completed
+    # The exchange: K frames' tiles per rank go out in ONE gather (fewer, larger collectives: a gather
+    # costs ~35 us of fixed enqueue / cross-stream work, half a frame at this size). Two batch buffers:
+    # the RCCL gather of batch j runs (on RCCL's own stream) while batch j+1 renders; a buffer is reused
+    # only after the gather that reads or fills it has completed.
+    K = max(1, args.frames_per_exchange) if dist_on else 1
     nbuf = 1 if (not dist_on or args.no_overlap) else 2
     gdev = torch.device("cpu") if gloo else dev
     # every step renders the f64 canvas tile (resident in HBM, Canvas::get_pixel semantics) AND its
     # 8-bit quantisation; the exchange moves one of the two
     gdtype = torch.uint8 if args.gather == "u8" else torch.float64
-    tile_bufs = [torch.zeros((rows_max, W, 3), dtype=torch.float64, device=dev) for _ in range(nbuf)]
-    tile8_bufs = [torch.zeros((rows_max, W, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    canvases = [torch.empty((world_size * rows_max, W, 3), dtype=gdtype, device=gdev) for _ in range(nbuf)] \
-        if (rank == 0 and dist_on) else [None] * nbuf
+    tile_bufs = [torch.zeros((K, rows_max, W, 3), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+    tile8_bufs = [torch.zeros((K, rows_max, W, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    root = rank == 0 and dist_on
+    # gather destination on rank 0: rank-major, (N, K, rows_max, W, 3) flattened over the first three axes
+    canvases = [torch.empty((world_size * K * rows_max, W, 3), dtype=gdtype, device=gdev) if root else None for _ in range(nbuf)]
     bands = [tiles.band_views(c, world_size) if c is not None else None for c in canvases]
-    # interleaved bands: the gather delivers rank-major bands; rank 0 un-deals them into image order
-    frames = [torch.empty_like(c) for c in canvases] if (banded and rank == 0) else None
-    undeal = [tiles.deinterleave_views(c, f, world_size) for c, f in zip(canvases, frames)] if frames is not None else None
-    # (the un-deal copy stays on the launch stream: a side stream would hide its ~8 us of GPU time but costs
-    # more than that in host calls per frame, and at this frame size rank 0 is host-bound)
+    # rank 0 turns what the gather delivers into K row-major frames with one strided device copy
+    # (not needed when K == 1 and the ranks own contiguous rows: the gather then lands every tile in place)
+    need_copy = root and (banded or K > 1)
+    frames = [torch.empty((K, world_size * rows_max, W, 3), dtype=gdtype, device=gdev) for _ in range(nbuf)] if need_copy else None
+    if need_copy:
+        per = rows_max // tiles.BAND_ROWS
+        if banded:   # (N, K, per, 8) -> (K, per, N, 8): frame-major, bands back in image order
+            undeal = [(f.view(K, per, world_size, tiles.BAND_ROWS, W, 3),
+                       c.view(world_size, K, per, tiles.BAND_ROWS, W, 3).permute(1, 2, 0, 3, 4, 5)) for c, f in zip(canvases, frames)]
+        else:        # (N, K, rows) -> (K, N, rows)
+            undeal = [(f.view(K, world_size, rows_max, W, 3), c.view(world_size, K, rows_max, W, 3).permute(1, 0, 2, 3, 4))
+                      for c, f in zip(canvases, frames)]
+    # (the copy stays on the launch stream: a side stream would hide its few us of GPU time but costs
+    # more than that in host calls, and at this frame size rank 0 is host-bound)
     pending = [None] * nbuf
     state = {"k": 0}
 
     def step():
-        b = state["k"] % nbuf
-        state["k"] += 1
-        if pending[b] is not None:
-            finish(b)               # current stream waits for the gather that last used buffer b
-        tile, tile8 = tile_bufs[b], tile8_bufs[b]
+        k = state["k"]
+        state["k"] = k + 1
+        slot, b = k % K, (k // K) % nbuf
+        if slot == 0 and pending[b] is not None:
+            finish(b)               # the launch stream waits for the gather that last used batch buffer b
+        tile, tile8 = tile_bufs[b][slot], tile8_bufs[b][slot]
         if banded:
             dworld.render_bands(cam, rank, world_size, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
         else:
             dworld.render_rows(cam, y0, y1, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
-        if dist_on:
-            src = tile8 if args.gather == "u8" else tile
-            src = src.cpu() if gloo else src
-            work = tiles.gather_tiles(src, canvases[b], world_size, rank, async_op=not args.no_overlap, bands=bands[b])
-            if work is not None:
-                pending[b] = work
-            elif frames is not None:
-                undeal[b][0].copy_(undeal[b][1])
+        if dist_on and slot == K - 1:
+            exchange(b)
+
+    def exchange(b):
+        src = (tile8_bufs[b] if args.gather == "u8" else tile_bufs[b]).view(K * rows_max, W, 3)
+        src = src.cpu() if gloo else src
+        work = tiles.gather_tiles(src, canvases[b], world_size, rank, async_op=not args.no_overlap, bands=bands[b])
+        if work is not None:
+            pending[b] = work
+        elif need_copy:
+            undeal[b][0].copy_(undeal[b][1])
 
     def finish(b):
         work, pending[b] = pending[b], None
-        work.wait()                 # the launch stream waits for the gather (its tile buffer is rendered into next)
-        if frames is not None:      # rank 0: bands back into image order (one strided device copy)
+        work.wait()
+        if need_copy:
             undeal[b][0].copy_(undeal[b][1])
 
     def drain():
+        k = state["k"]
+        state["last"] = k - 1
+        if dist_on and k % K != 0:  # a partly filled batch: exchange it as it is (the unused slots carry old frames)
+            exchange(((k - 1) // K) % nbuf)
+            state["k"] = k + (K - k % K)
         for b in range(nbuf):
             if pending[b] is not None:
                 finish(b)
@@ -213,6 +237,19 @@ def main():
     times = ctx.kernel_times_ms(min(args.steps, 1024))   # the timed steps (the newest 1024 of them if more)
     kernel_ms = float(times.mean()) if len(times) else 0.0
     last_ms = float(times[-1]) if len(times) else 0.0
+    # outside the timed region: the last frame rank 0 assembled from the gathered tiles must be the
+    # frame one GPU renders on its own, bit for bit
+    exchange_check = None
+    if root and state.get("last", -1) >= 0:
+        k = state["last"]
+        slot, b = k % K, (k // K) % nbuf
+        got = (frames[b][slot] if need_copy else canvases[b])[:H]
+        ref = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
+        ref8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+        dworld.render_rows(cam, 0, H, ref.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=ref8.data_ptr())
+        torch.cuda.synchronize(dev)
+        want = ref8 if args.gather == "u8" else ref
+        exchange_check = "ok" if torch.equal(got.to(want.device), want) else "MISMATCH"
     agg = torch.tensor([elapsed, float(st["rays_primary"]), float(st["rays_shadow"]), float(st["rays_reflect"] + st["rays_refract"]),
                         kernel_ms], dtype=torch.float64, device=torch.device("cpu") if gloo else dev)
     if dist_on:
@@ -253,7 +290,8 @@ def main():
                 "workload": workload,
                 "objects": len(world), "rows_per_gpu": rows, "parallelism": (f"{'8-row bands dealt round-robin' if banded else 'contiguous row tiles'} x{world_size} + {'gloo (rehearsal)' if gloo else 'RCCL'} gather of the "
                                                                           f"{'8-bit frame (Color::scale)' if args.gather == 'u8' else 'f64 canvas'} to rank 0"
-                                                                          + ("" if args.no_overlap else ", gather k overlapped with render k+1")) if dist_on else "single GPU",
+                                                                          + (f", one gather per {K} frames" if K > 1 else "")
+                                                                          + ("" if args.no_overlap else ", gather of batch j overlapped with the renders of batch j+1")) if dist_on else "single GPU",
                 "exchange_bytes_per_frame": (W * H * (3 if args.gather == "u8" else 24) * (world_size - 1) // world_size) if dist_on else 0,
                 "rays_per_frame_primary_shadow": int(round(rays_ps / steps)), "rays_per_frame_other": int(round(rays_other / steps)),
             },
@@ -274,6 +312,8 @@ def main():
         }
         if world_size > 1:
             out["config"]["kernel_ms_max_over_ranks"] = round(kernel_ms_max, 5)
+        if exchange_check is not None:
+            out["config"]["gathered_frame_vs_single_gpu_render"] = exchange_check
         if world_size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(world, cam, args.cpu_seconds)
         print(json.dumps(out), flush=True)

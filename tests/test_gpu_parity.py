@@ -398,6 +398,28 @@ def test_interleaved_bands_compose_the_frame(rtc, gpu, scenes, H):
     dw.close()
 
 
+@pytest.mark.parametrize("extra", [["--frames-per-exchange", "4"], ["--frames-per-exchange", "1", "--tiling", "rows"],
+                                   ["--gather", "f64", "--frames-per-exchange", "3"]])
+def test_bench_exchange_path_with_one_rank(extra):
+    """bench.py's distributed path (process group, batched RCCL gather, un-deal copy) with a single
+    rank: the frame rank 0 assembles must equal a plain render; the line carries the contract keys."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "11", "--warmup", "2",
+                        "--no-cpu-baseline", "--width", "320", "--height", "203", "--spheres", "20"] + extra,
+                       capture_output=True, text=True, timeout=300, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["gathered_frame_vs_single_gpu_render"] == "ok"
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line
+    assert line["steps"] == 11 and line["n_gpus"] == 1 and line["roofline"]["kernel_launches_timed"] == 11
+
+
 def test_pinned_host_canvas(rtc, gpu, scenes):
     """rtc_host_alloc canvases: same pixels as the pageable path, reusable between frames, freed
     with the last view."""
