@@ -227,6 +227,11 @@ rtc_status  rtc_canvas_write_ppm(const char *path, const double *rgb, uint32_t w
 size_t      rtc_canvas_format_ppm(const double *rgb, uint32_t width, uint32_t height, char *buf, size_t cap);
 /* Color::scale(c, 255) for n colour components (color.rs:100-114) on the host. */
 void        rtc_color_scale255(const double *components, size_t n, uint8_t *out);
+/* Canvas::to_imgbuf (canvas.rs:61-79), the pixel buffer behind write_to_file / frame_to_file:
+ * RGBA8, each channel Color::scale(c.powf(1/gamma), 255) (color.rs:55-65; the reciprocal taken in
+ * f32 as the reference does), alpha 255. Canvas::new sets gamma = 1.0 (canvas.rs:30). `out` holds
+ * width*height*4 bytes. Host. */
+void        rtc_canvas_to_rgba8(const double *rgb, uint32_t width, uint32_t height, float gamma, uint8_t *out);
 
 /* ==== [device] the hot path on one MI355X ========================================== */
 

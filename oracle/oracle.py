@@ -82,6 +82,7 @@ def lib() -> C.CDLL:
             "orc_render": (None, [PS, U32, PL, PC, U32, U32, U32, PD, U32, C.c_int, C.POINTER(RtcStats)]),
             "orc_format_ppm": (C.c_size_t, [PD, U32, U32, C.c_char_p, C.c_size_t]),
             "orc_color_scale": (I32, [D, I32]),
+            "orc_canvas_to_rgba8": (None, [PD, U32, U32, C.c_float, C.POINTER(C.c_uint8)]),
         }
         for name, (res, args) in sig.items():
             fn = getattr(L, name)

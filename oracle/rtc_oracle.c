@@ -823,6 +823,15 @@ int32_t orc_color_scale(double component, int32_t scale) { /* color.rs:100-114 *
     return i;
 }
 
+void orc_canvas_to_rgba8(const double *rgb, uint32_t width, uint32_t height, float gamma, uint8_t *out) {
+    /* canvas.rs:61-79 with color.rs:55-65: scale(c.powf(gamma.recip().into()), 255), alpha u8::MAX */
+    const float recip = 1.0f / gamma;
+    for (size_t i = 0; i < (size_t)width * height; i++) {
+        for (int k = 0; k < 3; k++) out[i * 4 + k] = (uint8_t)orc_color_scale(pow(rgb[i * 3 + k], (double)recip), 255);
+        out[i * 4 + 3] = 255;
+    }
+}
+
 size_t orc_format_ppm(const double *rgb, uint32_t width, uint32_t height, char *buf, size_t cap) {
     /* canvas.rs:86-109 */
     size_t pos = 0;

@@ -111,6 +111,7 @@ void   orc_render(const rtc_shape *shapes, uint32_t n, const rtc_light *light,
                   const rtc_camera *cam, uint32_t mode, uint32_t y0, uint32_t y1,
                   double *rgb, uint32_t nthreads, int streaming, rtc_stats *stats);
 /* Canvas::write_to_file_simple (canvas.rs:86-109) into memory; returns bytes needed. */
+void orc_canvas_to_rgba8(const double *rgb, uint32_t width, uint32_t height, float gamma, uint8_t *out);
 size_t orc_format_ppm(const double *rgb, uint32_t width, uint32_t height, char *buf, size_t cap);
 /* Color::scale (color.rs:100-114). */
 int32_t orc_color_scale(double component, int32_t scale);

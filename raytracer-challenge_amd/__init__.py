@@ -241,6 +241,15 @@ def format_ppm(rgb: np.ndarray) -> bytes:
     return buf.raw[:need]
 
 
+def to_rgba8(canvas: np.ndarray, gamma: float = 1.0) -> np.ndarray:
+    """Canvas::to_imgbuf (canvas.rs:61-79): (H, W, 4) uint8, gamma-corrected, alpha 255."""
+    c = np.ascontiguousarray(canvas, dtype=np.float64)
+    h, w = c.shape[0], c.shape[1]
+    out = np.empty((h, w, 4), dtype=np.uint8)
+    lib().rtc_canvas_to_rgba8(c.ctypes.data_as(C.POINTER(C.c_double)), w, h, gamma, out.ctypes.data_as(C.POINTER(C.c_uint8)))
+    return out
+
+
 def color_scale255(rgb: np.ndarray) -> np.ndarray:
     """Color::scale(c, 255) (color.rs:100-114) element-wise on the host."""
     a = np.ascontiguousarray(rgb, dtype=np.float64)

@@ -82,6 +82,7 @@ PROTOTYPES = {
     "rtc_canvas_write_ppm": (C.c_int32, [C.c_char_p, PD, U32, U32]),
     "rtc_canvas_format_ppm": (C.c_size_t, [PD, U32, U32, C.c_char_p, C.c_size_t]),
     "rtc_color_scale255": (None, [PD, C.c_size_t, C.POINTER(C.c_uint8)]),
+    "rtc_canvas_to_rgba8": (None, [PD, U32, U32, C.c_float, C.POINTER(C.c_uint8)]),
     "rtc_context_create": (C.c_int32, [C.c_int32, VP, C.POINTER(VP)]),
     "rtc_context_destroy": (None, [VP]),
     "rtc_context_synchronize": (C.c_int32, [VP]),

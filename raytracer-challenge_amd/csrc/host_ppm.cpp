@@ -3,6 +3,7 @@
 // wrapping, each component quantised by Color::scale (ch1/src/color.rs:100-114).
 #include "rtc.h"
 
+#include <cmath>
 #include <cstdio>
 #include <string>
 
@@ -69,6 +70,18 @@ size_t rtc_canvas_format_ppm(const double *rgb, uint32_t width, uint32_t height,
 void rtc_color_scale255(const double *components, size_t n, uint8_t *out) {
     if (!components || !out) return;
     for (size_t i = 0; i < n; ++i) out[i] = static_cast<uint8_t>(scale255(components[i]));
+}
+
+void rtc_canvas_to_rgba8(const double *rgb, uint32_t width, uint32_t height, float gamma, uint8_t *out) {
+    if (!rgb || !out) return;
+    // Color::{red,green,blue}_scaled_gamma color.rs:55-65: scale(c.powf(gamma.recip().into()), 255);
+    // the reciprocal is taken in f32 and widened, as in the reference
+    const double e = static_cast<double>(1.0f / gamma);
+    const size_t n = static_cast<size_t>(width) * height;
+    for (size_t i = 0; i < n; ++i) {
+        for (int k = 0; k < 3; ++k) out[i * 4 + k] = static_cast<uint8_t>(scale255(std::pow(rgb[i * 3 + k], e)));
+        out[i * 4 + 3] = 255; // std::u8::MAX canvas.rs:74
+    }
 }
 
 rtc_status rtc_canvas_write_ppm(const char *path, const double *rgb, uint32_t width, uint32_t height) {

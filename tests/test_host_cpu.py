@@ -166,6 +166,23 @@ def test_color_scale255_matches_oracle(rtc, O):
     assert np.array_equal(got, want)
 
 
+def test_to_rgba8_matches_oracle_and_gamma_one_is_plain_scale(rtc, O):
+    """Canvas::to_imgbuf (canvas.rs:61-79, color.rs:55-65): product vs oracle for several gammas;
+    with Canvas::new's gamma = 1.0 the bytes are Color::scale's (pow(x, 1) == x)."""
+    import ctypes as C
+    rng = np.random.default_rng(9)
+    img = rng.uniform(-0.2, 1.3, (7, 11, 3))
+    img[0, 0] = (float("nan"), float("inf"), -0.0)
+    img[0, 1] = (0.0, 1.0, 254.9999 / 255)
+    for gamma in (1.0, 2.2, 0.5, 1.8):
+        got = rtc.to_rgba8(img, gamma)
+        want = np.empty((7, 11, 4), dtype=np.uint8)
+        O.lib().orc_canvas_to_rgba8(img.ctypes.data_as(C.POINTER(C.c_double)), 11, 7, gamma, want.ctypes.data_as(C.POINTER(C.c_uint8)))
+        assert np.array_equal(got, want), gamma
+        assert (got[..., 3] == 255).all()
+    assert np.array_equal(rtc.to_rgba8(img, 1.0)[..., :3], rtc.color_scale255(img).reshape(7, 11, 3))
+
+
 def test_yaml_loader_builds_the_reference_constructors_world(rtc, O):
     """The loader's output equals a World built by hand with the reference's constructor order
     (SURVEY.md App. C): floor = Plane(identity.rotation_y(0.31415)), walls, spheres ..."""
