@@ -332,7 +332,10 @@ def test_quantised_rows_match_color_scale(rtc, gpu, O, scenes):
     import torch
     # 160x90 / 96x72 / 64x48: 16-byte store path; 50x37 and 33x9: partial tiles and the unaligned fallback
     for (w, cam) in (scenes.synthetic(40, 160, 90), scenes.test8(96, 72), scenes.synthetic(12, 64, 48, samples=4),
-                     scenes.synthetic(10, 50, 37), scenes.synthetic(5, 33, 9, samples=4)):
+                     scenes.synthetic(10, 50, 37), scenes.synthetic(5, 33, 9, samples=4),
+                     # frame-stack kernels store per wave (8x8 parts): aligned, 8-byte-only, and ragged widths
+                     scenes.synthetic(10, 40, 24, reflective=True), scenes.synthetic(10, 44, 21, reflective=True),
+                     scenes.synthetic(10, 50, 37, reflective=True), scenes.test8(77, 45), scenes.test8(33, 9, samples=4)):
         dw = gpu.upload(w)
         H, W = cam.vsize, cam.hsize
         f = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda:0")
