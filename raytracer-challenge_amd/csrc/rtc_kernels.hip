@@ -918,7 +918,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             // ---- World::intersect + get_hit (shape.rs:677-683, 220-232), streaming form ----
             double best = __builtin_inf();
             int hidx = -1, hroot = 0;
-            Bundle B;
+            Bundle B{}; // every field defined: an undefined field turns into a value carried around the pass loop
             B.off = true;
             if constexpr (IS_CULL(SRC)) {
                 if (ballot(tracing) != 0ull) {
@@ -1019,7 +1019,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     bool have_all = false, have_oth = false;
                     double key_all = 0., key_oth = 0.;
                     int idx_all = -1, idx_oth = -1;
-                    Bundle Ball; // entries with t < 0 matter here: visit every object
+                    Bundle Ball{}; // entries with t < 0 matter here: visit every object
                     Ball.off = true;
                     for_each_object<SRC>(P, T, L, need, Ball, [&](int j, auto m, uint32_t kind, auto pr) {
                         if (need) {
@@ -1056,7 +1056,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             STAMP(4); // hit record + shadow ray
             bool sh_pending = hit, shadowed = false;
             c_shadow += popc64(ballot(hit));
-            Bundle Bs;
+            Bundle Bs{};
             Bs.off = true;
             if constexpr (IS_CULL(SRC)) {
                 // the segment over_point -> light, walked from the light: apex = light (shared)
