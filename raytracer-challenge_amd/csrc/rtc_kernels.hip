@@ -5,14 +5,17 @@
 //
 // Design:
 //  * one thread per pixel; a wave owns an 8x8 pixel tile (coherent hit / miss / shadow
-//    decisions), a 256-thread workgroup a 32x8 tile; blockIdx is remapped so that the
-//    workgroups of one XCD cover a contiguous band of the image.
+//    decisions), a 256-thread workgroup a 32x8 tile; tile = workgroup id, which the hardware
+//    deals round-robin over the 8 XCDs (an even share of the image for each, RTC_TILE_ORDER).
 //  * every value is IEEE f64 evaluated in the reference's operation order; the file is
 //    compiled with -ffp-contract=off, so results are bit-identical to the CPU path apart
 //    from pow() (material.rs:355).
-//  * the object loop is wave-uniform: records come either through the scalar cache into
-//    SGPRs (SRC_SMEM, small worlds) or from LDS tiles shared by the workgroup (SRC_LDS1 one
-//    tile, SRC_LDSN many tiles with a barrier per tile, for worlds that exceed LDS).
+//  * the object loop is wave-uniform. Default (SRC_CULL, SRC_CULL2 above 256 objects): a
+//    conservative per-wave cull — 64 objects (or groups of 64) at a time, one bounding sphere per
+//    lane against the wave's ray bundle, __ballot, exact tests only for the survivors, their
+//    records fetched by uniform index through the scalar cache into SGPRs. Brute-force variants
+//    kept for A/B (RTC_FLAG_NO_CULL): records through the scalar cache (SRC_SMEM) or from LDS
+//    tiles shared by the workgroup (SRC_LDS1 one tile, SRC_LDSN many tiles with a barrier each).
 //  * the sorted Intersections list of the reference (shape.rs:167-237) is replaced by its
 //    streaming equivalent: running minimum over t >= 0 with first-inserted-wins ties
 //    (closest hit), any-hit with early exit (shadow), and an "open set" pass for n1/n2
@@ -57,14 +60,14 @@
 #define RTC_TILE_ORDER 1
 #endif
 // 2nd argument of __launch_bounds__ = minimum waves per SIMD (caps VGPRs: 5 -> 96, 4 -> 128,
-// 3 -> 168, 2 -> 256). Measured on the north-star scene (culled flat kernel, built with
-// -disable-machine-licm, 112 VGPRs uncapped): 4 -> 0.120 ms, 5 -> 0.113 ms, 6 -> 0.121 ms.
+// 3 -> 168, 2 -> 256). Measured on the north-star scene (culled flat kernel, 90 VGPRs):
+// 4 -> 0.0784 ms, 5 -> 0.0736 ms, 6 -> 0.0882 ms.
 // Kernels that carry the reflection/refraction frame stack: see RTC_WAVES_PER_SIMD_STACK.
 #ifndef RTC_WAVES_PER_SIMD
 #define RTC_WAVES_PER_SIMD 5
 #endif
-// Frame-stack kernels on a reflective 2048x2048 / 100-sphere scene: 2 -> 3.43 ms, 3 -> 2.55,
-// 4 -> 2.22, 5 -> 2.51, 6 -> 2.77.
+// Frame-stack kernels (124 VGPRs) on a reflective 2048x2048 / 100-sphere scene: 4 -> 0.871 ms,
+// 5 -> 0.870, 6 -> 0.862 (forcing more waves trades spills for occupancy: a wash).
 #ifndef RTC_WAVES_PER_SIMD_STACK
 #define RTC_WAVES_PER_SIMD_STACK 4
 #endif
