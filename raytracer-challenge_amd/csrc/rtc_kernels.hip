@@ -42,9 +42,11 @@
 // that always get it. Shadow segments in large worlds (two-level cull): the wave-level bundle of a
 // dense world keeps ~17 candidates per pass of which each lane's own segment touches few — 1000
 // spheres 0.535 -> 0.423 ms, 10 000 spheres 0.560 -> 0.462 ms; at 100 objects (one-level cull, ~2
-// candidates per pass) the filter costs more than it saves (0.0754 -> 0.0767 ms).
+// candidates per pass) the filter costs more than it saves (0.0754 -> 0.0767 ms). The frame-stack
+// kernels take it too: shadow segments from scattered secondary hits (6.7 exact tests per pass
+// without it), reflective 1080p 0.551 -> 0.536 ms.
 #ifndef RTC_SHADOW_LANE_FILTER
-#define RTC_SHADOW_LANE_FILTER(SRC) ((SRC) == SRC_CULL2)
+#define RTC_SHADOW_LANE_FILTER(SRC, REFL) ((SRC) == SRC_CULL2 || (REFL))
 #endif
 #ifndef RTC_PRIMARY_LANE_FILTER
 #define RTC_PRIMARY_LANE_FILTER(SRC) false
@@ -86,10 +88,14 @@ struct V3 {
 // library; the stamped build's run time is not meaningful, only the shares are.
 #ifdef RTC_STAMPS
 #define DIAG(i, v) do { diag_c[i] += (v); } while (0)
+#define DIAG_FILTER(p) do { if (p) *(p) += 1u; } while (0)
+#define DIAG_PTR(i) (&diag_c[i])
 #define STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp_t[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #define DIAG(i, v) do { } while (0)
+#define DIAG_FILTER(p) do { } while (0)
+#define DIAG_PTR(i) ((unsigned *)nullptr)
 #endif
 
 DEVI V3 mk(double x, double y, double z) { V3 v; v.x = x; v.y = y; v.z = z; return v; }
@@ -575,7 +581,7 @@ DEVI int take_min_key(unsigned long long &mask, float key, float &kmin) {
 
 template <int SRC, bool LANE_FILTER = false, class PP, class F, class SK = NoSkip>
 DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool lane_needs, const Bundle &B, F &&f,
-                          V3 fro = V3{0., 0., 0.}, V3 frd = V3{0., 0., 0.}, SK skip = SK{}) {
+                          V3 fro = V3{0., 0., 0.}, V3 frd = V3{0., 0., 0.}, SK skip = SK{}, unsigned *nfilt = nullptr) {
     constexpr bool ORDERED = !__is_same(SK, NoSkip);
     if constexpr (SRC == SRC_CULL) {
         // One-level cull (small worlds): 64 objects at a time, each lane tests one object's sphere
@@ -592,6 +598,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
                 const uint32_t jj = base + (uint32_t)__builtin_ctzll(mask);
                 mask &= mask - 1ull;
                 if constexpr (LANE_FILTER) {
+                    DIAG_FILTER(nfilt);
                     if (ballot(lane_needs && ray_touches(fro, frd, T.bound[jj])) == 0ull) continue;
                 }
                 const DevIsect *rec = T.isect + jj;
@@ -638,6 +645,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
                         mask &= mask - 1ull;
                     }
                     if constexpr (LANE_FILTER) {
+                        DIAG_FILTER(nfilt);
                         if (ballot(lane_needs && ray_touches(fro, frd, T.bound_s[jj])) == 0ull) continue;
                     }
                     const DevIsect *rec = T.isect_s + jj;
@@ -951,7 +959,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     DIAG(2, 1u);
                     if (tracing) closest_world(kind, m, ro, rd, j, best, hidx, hroot);
                     return true;
-                }, ro, rd);
+                }, ro, rd, NoSkip{}, DIAG_PTR(6));
 #endif
             } else if (SRC == SRC_CULL2 && !PROBE && shared_origin && first) {
                 // primary rays of a large world: start at the apex, unit direction -> ordered walk with early stop
@@ -1071,13 +1079,13 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             STAMP(5); // shadow bundle built
             DIAG(3, ballot(hit) != 0ull ? 1u : 0u);
             DIAG(4, (ballot(hit) != 0ull && Bs.off) ? 1u : 0u);
-            for_each_object<SRC, RTC_SHADOW_LANE_FILTER(SRC)>(P, T, L, sh_pending, Bs, [&](int j, auto m, uint32_t kind, auto pr) {
+            for_each_object<SRC, RTC_SHADOW_LANE_FILTER(SRC, REFL)>(P, T, L, sh_pending, Bs, [&](int j, auto m, uint32_t kind, auto pr) {
                 DIAG(5, 1u);
                 if (sh_pending) {
                     if (occludes_world(kind, m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
                 }
                 return ballot(sh_pending) != 0ull;
-            }, over, sdir);
+            }, over, sdir, NoSkip{}, DIAG_PTR(7));
 
             STAMP(6); // shadow resolved
             // keep the material / pattern loads of the lighting stage BELOW the shadow loop: hoisted

@@ -40,4 +40,5 @@ for i, nm in enumerate(names):
     print(f"  {nm:28s} {out[8 + i] / max(tot, 1) * 100:5.1f} %   {out[8 + i] / NW:9.0f} ticks/wave")
 d = [out[16 + i] for i in range(8)]
 print(f"per wave: closest passes {d[0] / NW:.2f} (unbounded bundle {d[1] / NW:.2f}), exact tests/closest pass {d[2] / max(d[0], 1):.2f}; "
-      f"shadow passes {d[3] / NW:.2f} (unbounded {d[4] / NW:.2f}), exact tests/shadow pass {d[5] / max(d[3], 1):.2f}")
+      f"shadow passes {d[3] / NW:.2f} (unbounded {d[4] / NW:.2f}), exact tests/shadow pass {d[5] / max(d[3], 1):.2f}; "
+      f"per-lane prefilter evaluations per wave: closest {d[6] / NW:.1f}, shadow {d[7] / NW:.1f}")
