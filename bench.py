@@ -63,6 +63,13 @@ def parse():
                          "reference consumes) or the raw f64 canvas (24 B/pixel; xGMI-ingest bound at this frame size)")
     ap.add_argument("--frames-per-exchange", type=int, default=8,
                     help="N>1: how many frames' tiles each rank sends per RCCL gather (1 = a gather per frame)")
+    ap.add_argument("--streams", type=int, default=0,
+                    help="frames in flight: consecutive frames are launched round-robin on this many HIP streams, so a "
+                         "launch that cannot fill the chip (a rank's 1/N of the frame) overlaps the next one. "
+                         "0 = 1 stream for the single-GPU run (clean per-kernel timing), up to 3 for N > 1 "
+                         "(as many as are measured to run side by side)")
+    ap.add_argument("--no-pipelined-probe", action="store_true",
+                    help="single GPU: skip the extra, informational two-frames-in-flight measurement")
     ap.add_argument("--tiling", default="bands", choices=["bands", "rows"],
                     help="how the rows are cut across ranks: 8-row bands dealt round-robin (even work per rank; rank 0 "
                          "un-deals them after the gather) or one contiguous range of rows per rank")
@@ -139,15 +146,25 @@ def main():
     rows_max = tiles.packed_rows(H, world_size) if banded else tiles.rows_per_rank(H, world_size)
     rows_mine = (sum(min(8, H - 8 * b) for b in tiles.bands_of_rank(H, world_size, rank)) if banded else y1 - y0)
 
-    # launch on torch's current stream so that torch events and RCCL order against the kernels
+    # Stream 0 is torch's current stream (RCCL orders against it); further streams carry every S-th
+    # frame. One context (= one stream, one event ring, one counter block) per stream, the World uploaded
+    # into each (it is ~50 KB).
+    S = args.streams if args.streams > 0 else (3 if dist_on else 1)
     stream = torch.cuda.current_stream(dev)
-    ctx = rtc.Context(dev_index, stream=stream.cuda_stream)
-    dworld = ctx.upload(world)
+    # HIP multiplexes streams onto 4 hardware queues (GPU_MAX_HW_QUEUES; raising it made things slower
+    # here): a second render stream easily lands on the queue of the first and the two then serialise.
+    # So create a few candidates and MEASURE which of them run beside stream 0 (pick_overlapping_streams).
+    pool = 1 if S == 1 else S + 3
+    streams = [stream] + [torch.cuda.Stream(dev) for _ in range(pool - 1)]
+    ctxs = [rtc.Context(dev_index, stream=st_.cuda_stream) for st_ in streams]
+    dworlds = [c.upload(world) for c in ctxs]
+    ctx, dworld = ctxs[0], dworlds[0]
+    everything = list(zip(dworlds, ctxs))   # closed at the end, whichever streams end up in use
     # The exchange: K frames' tiles per rank go out in ONE gather (fewer, larger collectives: a gather
     # costs ~35 us of fixed enqueue / cross-stream work, half a frame at this size). Two batch buffers:
     # the RCCL gather of batch j runs (on RCCL's own stream) while batch j+1 renders; a buffer is reused
     # only after the gather that reads or fills it has completed.
-    K = max(1, args.frames_per_exchange) if dist_on else 1
+    K = max(1, args.frames_per_exchange) if dist_on else S   # frames in flight never share an output slot
     nbuf = 1 if (not dist_on or args.no_overlap) else 2
     gdev = torch.device("cpu") if gloo else dev
     # every step renders the f64 canvas tile (resident in HBM, Canvas::get_pixel semantics) AND its
@@ -180,17 +197,21 @@ def main():
         k = state["k"]
         state["k"] = k + 1
         slot, b = k % K, (k // K) % nbuf
-        if slot == 0 and pending[b] is not None:
-            finish(b)               # the launch stream waits for the gather that last used batch buffer b
-        tile, tile8 = tile_bufs[b][slot], tile8_bufs[b][slot]
-        if banded:
-            dworld.render_bands(cam, rank, world_size, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
-        else:
-            dworld.render_rows(cam, y0, y1, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
+        if slot == 0:
+            if pending[b] is not None:
+                finish(b)           # stream 0 waits for the gather that last used batch buffer b ...
+            for st_ in streams[1:]:
+                st_.wait_stream(stream)   # ... and the other streams wait for stream 0 (once per batch)
+        lane = k % len(dworlds)
+        if not dist_on:
+            slot = lane             # single GPU: one output slot per stream (frames on one stream are ordered)
+        render_on(lane, tile_bufs[b][slot], tile8_bufs[b][slot])
         if dist_on and slot == K - 1:
             exchange(b)
 
     def exchange(b):
+        for st_ in streams[1:]:
+            stream.wait_stream(st_)       # the gather (ordered after stream 0) needs every frame of the batch
         src = (tile8_bufs[b] if args.gather == "u8" else tile_bufs[b]).view(K * rows_max, W, 3)
         src = src.cpu() if gloo else src
         work = tiles.gather_tiles(src, canvases[b], world_size, rank, async_op=not args.no_overlap, bands=bands[b])
@@ -205,6 +226,50 @@ def main():
         if need_copy:
             undeal[b][0].copy_(undeal[b][1])
 
+    def render_on(i, tile, tile8):
+        if banded:
+            dworlds[i].render_bands(cam, rank, world_size, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
+        else:
+            dworlds[i].render_rows(cam, y0, y1, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
+
+    def pick_overlapping_streams(S=S):
+        """Keep S of the candidate streams: stream 0 plus those whose launches really run beside
+        stream 0's (two streams that share a hardware queue serialise). Measured, not assumed: pairs of
+        this rank's own launches on (stream 0, candidate) against pairs on stream 0 alone."""
+        if S == 1 or len(streams) == 1:
+            return 1
+        ta = [torch.zeros((rows_max, W, 3), dtype=torch.float64, device=dev) for _ in range(2)]
+        tq = [torch.zeros((rows_max, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
+
+        def pairs2(a, b, reps=24):
+            best = float("inf")
+            for _ in range(3):
+                torch.cuda.synchronize(dev)
+                t = time.perf_counter()
+                for _ in range(reps):
+                    render_on(a, ta[0], tq[0])
+                    render_on(b, ta[1], tq[1])
+                torch.cuda.synchronize(dev)
+                best = min(best, time.perf_counter() - t)
+            return best
+
+        pairs2(0, 0)
+        serial = pairs2(0, 0)
+        ratio0 = {j: pairs2(0, j) / serial for j in range(1, len(streams))}
+        keep = [0]
+        for j in sorted(ratio0, key=ratio0.get):        # greedy: a stream joins if it overlaps with every one kept so far
+            if len(keep) == S:
+                break
+            if ratio0[j] < 0.95 and all(pairs2(x, j) / serial < 0.95 for x in keep[1:]):
+                keep.append(j)
+        if os.environ.get("RTC_BENCH_DEBUG"):
+            print(f"rank {rank}: serial pair {serial * 1e3:.3f} ms; candidate/serial vs stream 0: "
+                  + ", ".join(f"{j}:{r:.2f}" for j, r in sorted(ratio0.items())) + f"; kept {keep}", file=sys.stderr)
+        streams[:] = [streams[j] for j in keep]
+        ctxs[:] = [ctxs[j] for j in keep]
+        dworlds[:] = [dworlds[j] for j in keep]
+        return len(keep)
+
     def drain():
         k = state["k"]
         state["last"] = k - 1
@@ -218,15 +283,18 @@ def main():
     if dist_on:                     # communicator set-up and first-use costs never land in the timed region,
         exchange(0)                 # whatever --warmup is
         drain()
+    in_flight = pick_overlapping_streams()   # streams (= frames in flight) actually used from here on
     for _ in range(args.warmup):
         step()
     drain()
-    ctx.reset_stats()
+    for c in ctxs:
+        c.reset_stats()
     # kernel duration: every launch carries its own pair of HIP events on the launch stream
     # (hipExtLaunchKernel start/stop events inside rtc_render_rows, read back after the timed region)
     if dist_on:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    k_start = state["k"]
     t0 = time.perf_counter()
     for k in range(args.steps):
         step()
@@ -236,10 +304,39 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
 
-    st = ctx.stats()
-    times = ctx.kernel_times_ms(min(args.steps, 1024))   # the timed steps (the newest 1024 of them if more)
+    st = {}
+    for c in ctxs:
+        for key, v in c.stats().items():
+            st[key] = st.get(key, 0) + v
+    # the timed steps (the newest 1024 per stream if more)
+    per_stream = [sum(1 for k in range(k_start, k_start + args.steps) if k % len(ctxs) == i) for i in range(len(ctxs))]
+    times = np.concatenate([c.kernel_times_ms(min(n_, 1024)) if n_ else np.zeros(0, np.float32) for n_, c in zip(per_stream, ctxs)])
     kernel_ms = float(times.mean()) if len(times) else 0.0
     last_ms = float(times[-1]) if len(times) else 0.0
+    # Single GPU, for information only (the line's value / roofline stay those of the one-stream run, whose
+    # per-kernel durations are what rocprofv3 shows): the same frames with two in flight on two HIP streams,
+    # so that one launch's tail and the next one's ramp-up overlap.
+    pipelined = None
+    if not dist_on and S == 1 and not args.no_pipelined_probe:
+        extra = [torch.cuda.Stream(dev) for _ in range(4)]
+        streams.extend(extra)
+        ctxs.extend(rtc.Context(dev_index, stream=st_.cuda_stream) for st_ in extra)
+        dworlds.extend(c.upload(world) for c in ctxs[1:])
+        everything.extend(zip(dworlds[1:], ctxs[1:]))
+        if pick_overlapping_streams(2) == 2:
+            outs = [(torch.zeros((rows_max, W, 3), dtype=torch.float64, device=dev), torch.zeros((rows_max, W, 3), dtype=torch.uint8, device=dev))
+                    for _ in range(2)]
+            for k in range(args.warmup):
+                render_on(k % 2, *outs[k % 2])
+            torch.cuda.synchronize(dev)
+            t1 = time.perf_counter()
+            for k in range(args.steps):
+                render_on(k % 2, *outs[k % 2])
+            torch.cuda.synchronize(dev)
+            dt = time.perf_counter() - t1
+            pipelined = {"streams": 2, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 4),
+                         "value": round((st["rays_primary"] + st["rays_shadow"]) / dt / 1e6, 3), "unit": "Mrays/s",
+                         "note": "two frames in flight on two HIP streams (bench.py --streams 2 makes this the measured run)"}
     # outside the timed region: the last frame rank 0 assembled from the gathered tiles must be the
     # frame one GPU renders on its own, bit for bit
     exchange_check = None
@@ -294,7 +391,8 @@ def main():
                 "objects": len(world), "rows_per_gpu": rows, "parallelism": (f"{'8-row bands dealt round-robin' if banded else 'contiguous row tiles'} x{world_size} + {'gloo (rehearsal)' if gloo else 'RCCL'} gather of the "
                                                                           f"{'8-bit frame (Color::scale)' if args.gather == 'u8' else 'f64 canvas'} to rank 0"
                                                                           + (f", one gather per {K} frames" if K > 1 else "")
-                                                                          + ("" if args.no_overlap else ", gather of batch j overlapped with the renders of batch j+1")) if dist_on else "single GPU",
+                                                                          + (f", {in_flight} frames in flight (HIP streams measured to run side by side)" if in_flight > 1 else "")
+                                                                          + ("" if args.no_overlap else ", gather of batch j overlapped with the renders of batch j+1")) if dist_on else ("single GPU" + (f", {in_flight} frames in flight (HIP streams measured to run side by side)" if in_flight > 1 else "")),
                 "exchange_bytes_per_frame": (W * H * (3 if args.gather == "u8" else 24) * (world_size - 1) // world_size) if dist_on else 0,
                 "rays_per_frame_primary_shadow": int(round(rays_ps / steps)), "rays_per_frame_other": int(round(rays_other / steps)),
             },
@@ -317,12 +415,15 @@ def main():
             out["config"]["kernel_ms_max_over_ranks"] = round(kernel_ms_max, 5)
         if exchange_check is not None:
             out["config"]["gathered_frame_vs_single_gpu_render"] = exchange_check
+        if pipelined is not None:
+            out["pipelined"] = pipelined
         if world_size == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(world, cam, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    dworld.close()
-    ctx.close()
+    for d_, c in everything:
+        d_.close()
+        c.close()
     if dist_on:
         dist.destroy_process_group()
 

@@ -27,3 +27,33 @@ for N in (1, 2, 4, 8):
             dw.render_bands(cam, r, N, f.data_ptr(), d_ptr8=q.data_ptr())
         res.append(float(ctx.kernel_times_ms(50).mean()))
     print(f"N={N}: kernel ms per rank: min {min(res):.4f} max {max(res):.4f}  -> ceiling {0.0735 / max(res):.2f}x of one GPU's 0.0735 ms frame")
+
+# Frames in flight: one rank's launches issued round-robin on S streams (wall clock per frame).
+import time  # noqa: E402
+
+pool = [torch.cuda.Stream() for _ in range(6)]
+ctxs = [ctx] + [rtc.Context(0, stream=s.cuda_stream) for s in pool]
+dws = [dw] + [c.upload(w) for c in ctxs[1:]]
+for N in (1, 2, 4, 8):
+    rows = tiles.packed_rows(H, N)
+    bufs = [(torch.zeros((rows, W, 3), dtype=torch.float64, device="cuda:0"), torch.zeros((rows, W, 3), dtype=torch.uint8, device="cuda:0")) for _ in range(len(dws))]
+
+    def run(idx, reps=200):
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for k in range(reps):
+                i = idx[k % len(idx)]
+                dws[i].render_bands(cam, 0, N, bufs[i][0].data_ptr(), d_ptr8=bufs[i][1].data_ptr())
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t) / reps)
+        return best * 1e3
+
+    base = run([0])
+    # order the candidates by how well they overlap with stream 0 (two streams may share a hardware queue)
+    order = sorted(range(1, len(dws)), key=lambda j: run([0, j], 60))
+    line = [f"S=1 {base:.4f}"]
+    for S in (2, 3, 4):
+        line.append(f"S={S} {run([0] + order[:S - 1]):.4f}")
+    print(f"N={N}: ms per frame of one rank, wall clock: " + ", ".join(line))
