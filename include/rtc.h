@@ -287,11 +287,16 @@ rtc_status  rtc_stats_read(rtc_context *ctx, rtc_stats *out);
 rtc_status  rtc_stats_reset(rtc_context *ctx);
 /* Kernel timing. Every rtc_render_rows launch carries its own pair of HIP events that receive
  * the dispatch's begin and end timestamps on the context stream (hipExtLaunchKernel: no marker
- * packets, the same quantity rocprofv3's kernel trace reports). The context keeps the most
- * recent 1024 pairs. rtc_kernel_times_ms writes the durations (ms) of the latest min(cap, kept)
+ * packets, the same quantity rocprofv3's kernel trace reports) unless rtc_context_set_timing says
+ * otherwise. The context keeps the most recent 1024 pairs. rtc_kernel_times_ms writes the durations (ms) of the latest min(cap, kept)
  * launches, oldest first, and their number to *n; rtc_last_kernel_ms is the newest one alone
  * (RTC_ERR_ARG if nothing was launched yet). Both wait for the newest launch to finish. */
 rtc_status  rtc_kernel_times_ms(rtc_context *ctx, float *out, uint32_t cap, uint32_t *n);
+/* Which launches carry an event pair: every `every`-th one (1 = all, the default; 0 = none). The
+ * events cost about 9 us of host time and 5 us of GPU time per launch, which matters to callers
+ * that issue many short launches (one rank's share of a frame); they sample instead. Also forgets
+ * the pairs recorded so far: the next launch is the first of a new series. */
+rtc_status  rtc_context_set_timing(rtc_context *ctx, uint32_t every);
 rtc_status  rtc_last_kernel_ms(rtc_context *ctx, float *ms);
 
 /* World::color_at(ray, remaining) (shape.rs:702-710) for `n` arbitrary host rays

@@ -52,6 +52,23 @@ def lib() -> C.CDLL:
     return _lib
 
 
+_fn_cache: dict = {}
+
+
+def _render_rows():
+    f = _fn_cache.get("rows")
+    if f is None:
+        f = _fn_cache["rows"] = lib().rtc_render_rows
+    return f
+
+
+def _render_bands():
+    f = _fn_cache.get("bands")
+    if f is None:
+        f = _fn_cache["bands"] = lib().rtc_render_bands
+    return f
+
+
 def _check(status: int, where: str, detail: str = "") -> None:
     if status != 0:
         raise RtcError(status, where, detail)
@@ -318,6 +335,10 @@ class Context:
         _check(lib().rtc_last_kernel_ms(self._h, C.byref(ms)), "rtc_last_kernel_ms")
         return ms.value
 
+    def set_timing(self, every: int) -> None:
+        """Time every `every`-th render launch (1 = all, 0 = none); see include/rtc.h."""
+        _check(lib().rtc_context_set_timing(self._h, every), "rtc_context_set_timing")
+
     def kernel_times_ms(self, last: int = 1024) -> np.ndarray:
         """Durations (ms) of the most recent `last` render launches, oldest first (include/rtc.h)."""
         buf = (C.c_float * max(1, last))()
@@ -401,15 +422,17 @@ class DeviceWorld:
                     d_ptr8: int | None = None) -> None:
         """Enqueue rows [y0, y1) into the DEVICE buffer at address `d_ptr` (no synchronisation);
         `d_ptr8` optionally receives the rows quantised to 8 bits (Color::scale)."""
-        _check(lib().rtc_render_rows(self.ctx._h, self._h, C.byref(cam), mode, y0, y1, C.c_void_p(d_ptr),
-                                     C.c_void_p(d_ptr8 or None), flags), "rtc_render_rows")
+        st = _render_rows()(self.ctx._h, self._h, cam, mode, y0, y1, d_ptr, d_ptr8, flags)  # launch path: no temporaries
+        if st != 0:
+            raise RtcError(st, "rtc_render_rows")
 
     def render_bands(self, cam: RtcCamera, first_band: int, band_stride: int, d_ptr: int, mode: int = MODE_RENDER_ASYNC,
                      flags: int = 0, d_ptr8: int | None = None) -> None:
         """Enqueue the 8-row bands first_band, first_band + band_stride, ... packed one after the
         other into the DEVICE buffer at `d_ptr` (interleaved row tiles, include/rtc.h)."""
-        _check(lib().rtc_render_bands(self.ctx._h, self._h, C.byref(cam), mode, first_band, band_stride, C.c_void_p(d_ptr),
-                                      C.c_void_p(d_ptr8 or None), flags), "rtc_render_bands")
+        st = _render_bands()(self.ctx._h, self._h, cam, mode, first_band, band_stride, d_ptr, d_ptr8, flags)
+        if st != 0:
+            raise RtcError(st, "rtc_render_bands")
 
     def color_at(self, rays: np.ndarray, remaining: int = 5, want_hits: bool = False, flags: int = 0):
         """World::color_at for an (n, 6) array of rays; returns rgb (n,3) [and the rtc_hit array]."""

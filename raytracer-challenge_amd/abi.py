@@ -97,6 +97,7 @@ PROTOTYPES = {
     "rtc_stats_read": (C.c_int32, [VP, C.POINTER(RtcStats)]),
     "rtc_stats_reset": (C.c_int32, [VP]),
     "rtc_kernel_times_ms": (C.c_int32, [VP, C.POINTER(C.c_float), U32, C.POINTER(U32)]),
+    "rtc_context_set_timing": (C.c_int32, [VP, U32]),
     "rtc_last_kernel_ms": (C.c_int32, [VP, C.POINTER(C.c_float)]),
     "rtc_color_at": (C.c_int32, [VP, VP, PD, U32, U32, U32, PD, C.POINTER(RtcHit)]),
     "rtc_device_arith": (C.c_int32, [VP, U32, PD, PD, U32, PD]),

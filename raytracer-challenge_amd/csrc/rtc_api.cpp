@@ -28,10 +28,14 @@ struct rtc_context {
     int device = -1;
     hipStream_t stream = nullptr;
     unsigned long long *d_counters = nullptr;
-    // ring of (begin, end) event pairs, one per k_trace launch of rtc_render_rows (created on first use)
+    // ring of (begin, end) event pairs, one per k_trace launch of rtc_render_rows / rtc_render_bands
+    // (all created with the context: creating them lazily put two hipEventCreate calls on the launch
+    // path of the first 1024 frames)
     static constexpr uint32_t EV_RING = 1024;
     hipEvent_t ev[EV_RING][2] = {};
-    uint64_t launches = 0;
+    uint64_t launches = 0; // render launches so far
+    uint64_t timed = 0;    // ... of which carried an event pair (ring position)
+    uint32_t time_every = 1; // rtc_context_set_timing
     // device canvas of rtc_render (host-canvas entry point): grow-only, reused between frames
     double *d_canvas = nullptr;
     size_t canvas_bytes = 0;
@@ -266,6 +270,12 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
         rtc_context_destroy(ctx);
         return RTC_ERR_DEVICE;
     }
+    for (auto &pair : ctx->ev)
+        for (hipEvent_t &e : pair)
+            if (hipEventCreate(&e) != hipSuccess) {
+                rtc_context_destroy(ctx);
+                return RTC_ERR_DEVICE;
+            }
     if (const char *e = std::getenv("RTC_SRC")) {
         const int v = std::atoi(e);
         if (v >= 0 && v <= 4) ctx->force_src = v;
@@ -511,12 +521,14 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     P.flags = flags;
     // per-render prologue table of the brute-force variants (the culled kernels do not use it)
     if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.vinv, ctx->stream));
-    hipEvent_t *pair = ctx->ev[ctx->launches % rtc_context::EV_RING];
-    if (!pair[0]) HIP_TRY(hipEventCreate(&pair[0]));
-    if (!pair[1]) HIP_TRY(hipEventCreate(&pair[1]));
+    // start/stop events cost ~9 us of host time and ~5 us of GPU time per launch (measured): callers
+    // that are launch-bound sample every n-th launch instead (rtc_context_set_timing)
+    const bool timed = ctx->time_every != 0 && ctx->launches % ctx->time_every == 0;
+    hipEvent_t *pair = ctx->ev[ctx->timed % rtc_context::EV_RING];
     HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y, lds_bytes, ctx->stream,
-                             pair[0], pair[1]));
+                             timed ? pair[0] : nullptr, timed ? pair[1] : nullptr));
     ++ctx->launches;
+    if (timed) ++ctx->timed;
     return RTC_OK;
 }
 
@@ -578,16 +590,24 @@ rtc_status rtc_stats_reset(rtc_context *ctx) {
     return RTC_OK;
 }
 
+rtc_status rtc_context_set_timing(rtc_context *ctx, uint32_t every) {
+    if (!ctx) return RTC_ERR_ARG;
+    ctx->time_every = every;
+    ctx->launches = 0; // the next launch is sampled (if any is), and the ring starts afresh
+    ctx->timed = 0;
+    return RTC_OK;
+}
+
 rtc_status rtc_kernel_times_ms(rtc_context *ctx, float *out, uint32_t cap, uint32_t *n) {
     if (!ctx || !n || (cap && !out)) return RTC_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
-    const uint64_t have = ctx->launches < rtc_context::EV_RING ? ctx->launches : rtc_context::EV_RING;
+    const uint64_t have = ctx->timed < rtc_context::EV_RING ? ctx->timed : rtc_context::EV_RING;
     const uint64_t take = have < cap ? have : cap;
     *n = (uint32_t)take;
     if (take == 0) return RTC_OK;
-    HIP_TRY(hipEventSynchronize(ctx->ev[(ctx->launches - 1) % rtc_context::EV_RING][1]));
+    HIP_TRY(hipEventSynchronize(ctx->ev[(ctx->timed - 1) % rtc_context::EV_RING][1]));
     for (uint64_t k = 0; k < take; ++k) {
-        hipEvent_t *pair = ctx->ev[(ctx->launches - take + k) % rtc_context::EV_RING];
+        hipEvent_t *pair = ctx->ev[(ctx->timed - take + k) % rtc_context::EV_RING];
         HIP_TRY(hipEventElapsedTime(&out[k], pair[0], pair[1]));
     }
     return RTC_OK;

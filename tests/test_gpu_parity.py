@@ -420,7 +420,7 @@ def test_bench_exchange_path_with_one_rank(extra):
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in line
-    assert line["steps"] == 11 and line["n_gpus"] == 1 and line["roofline"]["kernel_launches_timed"] == 11
+    assert line["steps"] == 11 and line["n_gpus"] == 1 and 2 <= line["roofline"]["kernel_launches_timed"] <= 11
 
 
 def test_pinned_host_canvas(rtc, gpu, scenes):
@@ -457,6 +457,15 @@ def test_kernel_times_ring(rtc, scenes):
     t = ctx.kernel_times_ms()
     assert len(t) == 5 and (t > 0).all() and (t < 50).all()
     assert len(ctx.kernel_times_ms(3)) == 3 and ctx.kernel_times_ms(3)[-1] == t[-1] == np.float32(ctx.last_kernel_ms())
+    ctx.set_timing(4)       # every 4th launch from now on, ring restarted
+    assert len(ctx.kernel_times_ms()) == 0
+    for _ in range(9):
+        dw.render(cam)
+    assert len(ctx.kernel_times_ms()) == 3   # launches 0, 4, 8
+    ctx.set_timing(0)
+    dw.render(cam)
+    assert len(ctx.kernel_times_ms()) == 0
+    ctx.set_timing(1)
     for _ in range(1030):   # wraps the 1024-pair ring
         dw.render(cam)
     t = ctx.kernel_times_ms(4096)
