@@ -61,7 +61,7 @@ def parse():
     ap.add_argument("--gather", default="u8", choices=["u8", "f64"],
                     help="what rank 0 collects: the 8-bit frame (Color::scale, 3 B/pixel - what every file writer of the "
                          "reference consumes) or the raw f64 canvas (24 B/pixel; xGMI-ingest bound at this frame size)")
-    ap.add_argument("--frames-per-exchange", type=int, default=8,
+    ap.add_argument("--frames-per-exchange", type=int, default=32,
                     help="N>1: how many frames' tiles each rank sends per RCCL gather (1 = a gather per frame)")
     ap.add_argument("--streams", type=int, default=0,
                     help="frames in flight: consecutive frames are launched round-robin on this many HIP streams, so a "
@@ -167,10 +167,13 @@ def main():
     ctx, dworld = ctxs[0], dworlds[0]
     everything = list(zip(dworlds, ctxs))   # closed at the end, whichever streams end up in use
     # The exchange: K frames' tiles per rank go out in ONE gather (fewer, larger collectives: a gather
-    # costs ~35 us of fixed enqueue / cross-stream work, half a frame at this size). Two batch buffers:
+    # costs ~35 us of fixed enqueue / cross-stream work, half a frame at this size; one rank's 1/8 of the
+    # frame: 20.4 us per frame at K = 8, 16.2 at 16, 14.3 at 32, 13.5 at 64, 12.9 without any exchange). Two batch buffers:
     # the RCCL gather of batch j runs (on RCCL's own stream) while batch j+1 renders; a buffer is reused
     # only after the gather that reads or fills it has completed.
     K = max(1, args.frames_per_exchange) if dist_on else S   # frames in flight never share an output slot
+    if dist_on:                     # a batch keeps K f64 tiles (+ their 8-bit frames) per buffer: stay within ~2 GB
+        K = max(1, min(K, int(2e9 // (rows_max * W * 24))))
     nbuf = 1 if (not dist_on or args.no_overlap) else 2
     gdev = torch.device("cpu") if gloo else dev
     # every step renders the f64 canvas tile (resident in HBM, Canvas::get_pixel semantics) AND its
