@@ -272,6 +272,18 @@ rtc_status  rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_came
 rtc_status  rtc_render_bands(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,
                              uint32_t mode, uint32_t first_band, uint32_t band_stride,
                              void *d_rgb, void *d_rgb8, uint32_t flags);
+/* Several cameras, one World, ONE launch: the frames of a camera move over a static scene (the
+ * reference's AddFrame loop orbits the camera, lua.rs / functions.lua:3-11), a stereo pair, or — with
+ * one process per GPU — several frames' worth of one rank's bands, so that a launch fills the chip
+ * even when a rank owns an eighth of the image. `cams[0..nviews)` must agree in hsize, vsize and
+ * samples; nviews <= RTC_MAX_VIEWS_PER_LAUNCH. Rows are selected as in rtc_render_bands
+ * (first_band = 0, band_stride = 1 for whole frames); view v is written `v * view_rows` rows
+ * below view 0 in d_rgb / d_rgb8 (view_rows >= the rows one view produces). Per pixel the result is
+ * exactly that of rtc_render_bands with the same camera. [device] */
+#define RTC_MAX_VIEWS_PER_LAUNCH 8u
+rtc_status  rtc_render_views(rtc_context *ctx, const rtc_world *w, const rtc_camera *cams, uint32_t nviews,
+                             uint32_t mode, uint32_t first_band, uint32_t band_stride,
+                             void *d_rgb, void *d_rgb8, uint32_t view_rows, uint32_t flags);
 /* Camera::render(&World) -> Canvas with host memory: renders all rows and copies the
  * canvas into `rgb` (vsize*hsize*3 doubles). Synchronous. `stats` may be NULL. */
 rtc_status  rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,

@@ -434,6 +434,16 @@ class DeviceWorld:
         if st != 0:
             raise RtcError(st, "rtc_render_bands")
 
+    def render_views(self, cams, first_band: int, band_stride: int, d_ptr: int, view_rows: int, mode: int = MODE_RENDER_ASYNC,
+                     flags: int = 0, d_ptr8: int | None = None) -> None:
+        """Enqueue ONE launch that renders every camera of `cams` (a list of RtcCamera, or a prebuilt
+        ctypes array of them) onto this World; view v lands `v * view_rows` rows below view 0
+        (rtc_render_views, include/rtc.h)."""
+        arr = cams if isinstance(cams, C.Array) else (RtcCamera * len(cams))(*cams)
+        st = lib().rtc_render_views(self.ctx._h, self._h, arr, len(arr), mode, first_band, band_stride, d_ptr, d_ptr8, view_rows, flags)
+        if st != 0:
+            raise RtcError(st, "rtc_render_views")
+
     def color_at(self, rays: np.ndarray, remaining: int = 5, want_hits: bool = False, flags: int = 0):
         """World::color_at for an (n, 6) array of rays; returns rgb (n,3) [and the rtc_hit array]."""
         r = np.ascontiguousarray(rays, dtype=np.float64).reshape(-1, 6)

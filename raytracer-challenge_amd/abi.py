@@ -91,6 +91,7 @@ PROTOTYPES = {
     "rtc_world_destroy": (None, [VP]),
     "rtc_render_rows": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, U32, VP, VP, U32]),
     "rtc_render_bands": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, U32, VP, VP, U32]),
+    "rtc_render_views": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, U32, U32, VP, VP, U32, U32]),
     "rtc_render": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, PD, C.POINTER(RtcStats)]),
     "rtc_host_alloc": (C.c_int32, [C.c_size_t, C.POINTER(VP)]),
     "rtc_host_free": (None, [VP]),

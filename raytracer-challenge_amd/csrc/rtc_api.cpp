@@ -218,14 +218,17 @@ DevBound bound_of(const rtc_shape &s) {
     return b;
 }
 
-void fill_camera(RenderParams &P, const rtc_camera *cam) {
-    P.W = cam->hsize;
-    P.H = cam->vsize;
-    P.samples = cam->samples ? cam->samples : 1;
-    P.half_width = cam->half_width;
-    P.half_height = cam->half_height;
-    P.pixel_size = cam->pixel_size;
-    std::memcpy(P.vinv, cam->view_inv, sizeof(double) * 12);
+void fill_camera(RenderParams &P, const rtc_camera *cam, uint32_t view = 0) {
+    if (view == 0) {
+        P.W = cam->hsize;
+        P.H = cam->vsize;
+        P.samples = cam->samples ? cam->samples : 1;
+    }
+    DevCamera &c = P.views[view];
+    c.half_width = cam->half_width;
+    c.half_height = cam->half_height;
+    c.pixel_size = cam->pixel_size;
+    std::memcpy(c.vinv, cam->view_inv, sizeof(double) * 12);
 }
 
 void fill_world(RenderParams &P, const rtc_world *w) {
@@ -498,12 +501,14 @@ void rtc_world_destroy(rtc_world *w) {
 // rows [y0, y1) in tile rows of 8, tile row k at image rows y0 + 8*k*band_stride; grid_y tile rows
 static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode, uint32_t y0,
                                 uint32_t y1, uint32_t band_stride, uint32_t grid_y, void *d_rgb, void *d_rgb8,
-                                uint32_t flags) {
+                                uint32_t flags, uint32_t nviews = 1, uint32_t view_rows = 0) {
     HIP_TRY(hipSetDevice(ctx->device));
     RenderParams P;
     std::memset(&P, 0, sizeof P);
     fill_world(P, w);
-    fill_camera(P, cam);
+    for (uint32_t v = 0; v < nviews; ++v) fill_camera(P, cam + v, v);
+    P.nviews = nviews;
+    P.view_rows = view_rows;
     P.y0 = y0;
     P.y1 = y1;
     P.mode = mode;
@@ -520,12 +525,12 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     choose_source(ctx, w->n, flags, &src, &P.tile_cap, &lds_bytes);
     P.flags = flags;
     // per-render prologue table of the brute-force variants (the culled kernels do not use it)
-    if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.vinv, ctx->stream));
+    if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.views[0].vinv, ctx->stream));
     // start/stop events cost ~9 us of host time and ~5 us of GPU time per launch (measured): callers
     // that are launch-bound sample every n-th launch instead (rtc_context_set_timing)
     const bool timed = ctx->time_every != 0 && ctx->launches % ctx->time_every == 0;
     hipEvent_t *pair = ctx->ev[ctx->timed % rtc_context::EV_RING];
-    HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y, lds_bytes, ctx->stream,
+    HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y * nviews, lds_bytes, ctx->stream,
                              timed ? pair[0] : nullptr, timed ? pair[1] : nullptr));
     ++ctx->launches;
     if (timed) ++ctx->timed;
@@ -619,6 +624,41 @@ rtc_status rtc_last_kernel_ms(rtc_context *ctx, float *ms) {
     const rtc_status st = rtc_kernel_times_ms(ctx, ms, 1, &n);
     if (st != RTC_OK) return st;
     return n == 1 ? RTC_OK : RTC_ERR_ARG;
+}
+
+static_assert(RTC_MAX_VIEWS == RTC_MAX_VIEWS_PER_LAUNCH, "include/rtc.h and rtc_device.h disagree");
+
+rtc_status rtc_render_views(rtc_context *ctx, const rtc_world *w, const rtc_camera *cams, uint32_t nviews, uint32_t mode,
+                            uint32_t first_band, uint32_t band_stride, void *d_rgb, void *d_rgb8, uint32_t view_rows,
+                            uint32_t flags) {
+    if (!ctx || !w || !cams || !d_rgb || w->ctx != ctx) return RTC_ERR_ARG;
+    if (nviews == 0 || nviews > RTC_MAX_VIEWS_PER_LAUNCH || band_stride == 0 || mode > RTC_MODE_RENDER_ASYNC) return RTC_ERR_ARG;
+    if (cams[0].hsize == 0 || cams[0].vsize == 0) return RTC_ERR_ARG;
+    for (uint32_t v = 1; v < nviews; ++v)
+        if (cams[v].hsize != cams[0].hsize || cams[v].vsize != cams[0].vsize ||
+            (cams[v].samples ? cams[v].samples : 1) != (cams[0].samples ? cams[0].samples : 1))
+            return RTC_ERR_ARG; // one grid, one sampling pattern per launch
+    const uint32_t nbands = (cams[0].vsize + RTC_BAND_ROWS - 1u) / RTC_BAND_ROWS;
+    if (first_band >= nbands) return RTC_OK;
+    const uint32_t mine = (nbands - first_band + band_stride - 1u) / band_stride;
+    if (view_rows < mine * RTC_BAND_ROWS) return RTC_ERR_ARG;
+    int src;
+    uint32_t cap;
+    size_t lds;
+    choose_source(ctx, w->n, flags, &src, &cap, &lds);
+    if (src != SRC_CULL && src != SRC_CULL2) {
+        // the brute-force variants keep a per-render table of the camera origin in object space: one view per launch
+        for (uint32_t v = 0; v < nviews; ++v) {
+            const rtc_status st = render_launch(ctx, w, cams + v, mode, first_band * RTC_BAND_ROWS, cams[0].vsize, band_stride, mine,
+                                                static_cast<double *>(d_rgb) + (size_t)v * view_rows * cams[0].hsize * 3u,
+                                                d_rgb8 ? static_cast<unsigned char *>(d_rgb8) + (size_t)v * view_rows * cams[0].hsize * 3u : nullptr,
+                                                flags);
+            if (st != RTC_OK) return st;
+        }
+        return RTC_OK;
+    }
+    return render_launch(ctx, w, cams, mode, first_band * RTC_BAND_ROWS, cams[0].vsize, band_stride, mine, d_rgb, d_rgb8, flags,
+                         nviews, view_rows);
 }
 
 rtc_status rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode, uint32_t flags,

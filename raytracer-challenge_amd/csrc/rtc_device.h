@@ -65,6 +65,13 @@ enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PI
 // sums the replicas (rtc_stats_read).
 enum { CNT_SLOTS = 256 };
 
+// One camera of a launch (camera.rs:17-27, the part ray_for_pixel reads).
+struct DevCamera {
+    double half_width, half_height, pixel_size;
+    double vinv[12];
+};
+enum { RTC_MAX_VIEWS = 8 };
+
 struct RenderParams {
     const DevIsect *isect;
     const uint32_t *kind;
@@ -83,8 +90,11 @@ struct RenderParams {
     double light_pos[3], light_int[3];
     // camera (camera.rs:17-27)
     uint32_t W, H, y0, y1, mode, samples;
-    double half_width, half_height, pixel_size;
-    double vinv[12];
+    // A launch renders `nviews` cameras of the same size onto the same World (rtc_render_views: the
+    // frames of a camera move, a stereo pair): workgroups [v*tiles, (v+1)*tiles) belong to view v and
+    // write `view_rows` rows further down the output buffers. One camera = views[0], nviews = 1.
+    DevCamera views[RTC_MAX_VIEWS];
+    uint32_t nviews, view_rows;
     double *out;                 // rows x W x 3, rows = y1-y0 (band_stride 1) or 8*grid_y (packed bands)
     unsigned char *out8;         // optional: the same rows quantised by Color::scale(c, 255)
     unsigned long long *counters; // CNT_N

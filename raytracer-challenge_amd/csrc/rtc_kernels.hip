@@ -846,13 +846,16 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
 #endif
 
     uint32_t px = 0, py = 0, ray_index = 0;
+    uint32_t view = 0, tbid = bid; // which camera of the launch, and the tile's index inside that view
     bool in_range, traced;
     if (probe) {
         ray_index = bid * RTC_BLOCK + threadIdx.x;
         in_range = ray_index < P.nrays;
         traced = in_range;
     } else {
-        const uint32_t bx = bid % P.grid_x, by = bid / P.grid_x;
+        const uint32_t tiles = P.grid_x * P.grid_y;
+        if (P.nviews > 1u) { view = bid / tiles; tbid = bid % tiles; }
+        const uint32_t bx = tbid % P.grid_x, by = tbid / P.grid_x;
         px = bx * 32u + wave * 8u + (lane & 7u);
         py = P.y0 + by * P.band_stride * 8u + (lane >> 3);
         in_range = px < P.W && py < P.y1;
@@ -884,7 +887,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     for (uint32_t s = 0; s < nsamples; ++s) {
         V3 ro, rd;
         bool shared_origin;
-        const auto &Pr = KP(P_arg); // ray-generation view: camera block
+        const auto &Pr = KP(P_arg).views[view]; // ray-generation view: this workgroup's camera block
         // ray origin of every primary ray: transform_point(view_inv, (0,0,0)) camera.rs:72
         V3 cam_origin = xpoint(Pr.vinv, mk(0., 0., 0.));
         cam_origin = mk(uniform_f64(cam_origin.x), uniform_f64(cam_origin.y), uniform_f64(cam_origin.z)); // same in every lane
@@ -1260,8 +1263,8 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t px0 = (bid % Po.grid_x) * 32u + wave * 8u, py0 = Po.y0 + (bid / Po.grid_x) * Po.band_stride * 8u,
-                               orow0 = (bid / Po.grid_x) * 8u; // first image row / first output row of the tile
+                const uint32_t px0 = (tbid % Po.grid_x) * 32u + wave * 8u, py0 = Po.y0 + (tbid / Po.grid_x) * Po.band_stride * 8u,
+                               orow0 = view * Po.view_rows + (tbid / Po.grid_x) * 8u; // first image row / first output row of the tile
                 const uint32_t cols = (px0 >= Po.W) ? 0u : ((Po.W - px0 < 8u) ? (Po.W - px0) : 8u); // valid pixels per row
                 const uint32_t rows = (Po.y1 - py0 < 8u) ? (Po.y1 - py0) : 8u;                       // valid tile rows
                 const size_t row_bytes = (size_t)Po.W * 24u;
@@ -1303,8 +1306,8 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 }
                 } else {
                 __syncthreads();
-                const uint32_t px0 = (bid % Po.grid_x) * 32u, py0 = Po.y0 + (bid / Po.grid_x) * Po.band_stride * 8u,
-                               orow0 = (bid / Po.grid_x) * 8u; // first image row / first output row of the tile
+                const uint32_t px0 = (tbid % Po.grid_x) * 32u, py0 = Po.y0 + (tbid / Po.grid_x) * Po.band_stride * 8u,
+                               orow0 = view * Po.view_rows + (tbid / Po.grid_x) * 8u; // first image row / first output row of the tile
                 const uint32_t cols = (Po.W - px0 < 32u) ? (Po.W - px0) : 32u;      // valid pixels per tile row
                 const uint32_t rows = (Po.y1 - py0 < 8u) ? (Po.y1 - py0) : 8u;      // valid tile rows
                 // f64 canvas: 16-byte pieces when every tile row is whole and 16-byte aligned

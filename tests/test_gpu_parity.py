@@ -423,6 +423,56 @@ def test_bench_exchange_path_with_one_rank(extra):
     assert line["steps"] == 11 and line["n_gpus"] == 1 and 2 <= line["roofline"]["kernel_launches_timed"] <= 11
 
 
+@pytest.mark.parametrize("reflective", [False, True])
+def test_views_of_one_launch_equal_separate_renders(rtc, gpu, scenes, reflective):
+    """rtc_render_views: several cameras in ONE launch (a camera orbit over a static World, as the
+    reference's AddFrame loop does, lua.rs) == the same cameras rendered one by one, bit for bit
+    (f64 canvas, 8-bit frame, ray counts); whole frames and one rank's bands; brute-force fallback."""
+    import torch
+    tiles = importlib.import_module(rtc.__name__ + ".tiles")
+    W, H = 160, 93
+    w, _ = scenes.synthetic(25, W, H, reflective=reflective)
+    cams = [rtc.camera(W, H, 0.7 + 0.05 * i, rtc.Matrix.make_view_transform((3.0 * math.sin(0.4 * i), 2.0, -8.0 + i), (0.0, 1.0, 5.0), (0.0, 1.0, 0.0)))
+            for i in range(5)]
+    dw = gpu.upload(w)
+    singles, total = [], {}
+    for c in cams:
+        img, st = dw.render(c, rtc.MODE_RENDER_ASYNC, with_stats=True)
+        singles.append(img)
+        for k, v in st.items():
+            total[k] = total.get(k, 0) + v
+    assert not np.array_equal(singles[0], singles[1])
+    for flags in (0, 1):
+        # whole frames: first_band 0, stride 1; views stacked with 4 spare rows between them
+        rows = tiles.n_bands(H) * 8 + 4
+        f = torch.full((5 * rows, W, 3), -1.0, dtype=torch.float64, device="cuda:0")
+        q = torch.full((5 * rows, W, 3), 9, dtype=torch.uint8, device="cuda:0")
+        gpu.reset_stats()
+        dw.render_views(cams, 0, 1, f.data_ptr(), rows, flags=flags, d_ptr8=q.data_ptr())
+        assert gpu.stats() == total
+        fh, qh = f.cpu().numpy(), q.cpu().numpy()
+        for v in range(5):
+            assert np.array_equal(fh[v * rows: v * rows + H], singles[v]), (flags, v)
+            assert np.array_equal(qh[v * rows: v * rows + H], rtc.color_scale255(singles[v]).reshape(H, W, 3)), (flags, v)
+            assert (fh[v * rows + tiles.n_bands(H) * 8: (v + 1) * rows] == -1.0).all()
+    # one rank's bands (rank 1 of 3) of every view
+    N, r = 3, 1
+    per = tiles.packed_rows(H, N)
+    f = torch.zeros((5 * per, W, 3), dtype=torch.float64, device="cuda:0")
+    dw.render_views(cams, r, N, f.data_ptr(), per)
+    one = torch.zeros((per, W, 3), dtype=torch.float64, device="cuda:0")
+    for v, c in enumerate(cams):
+        dw.render_bands(c, r, N, one.data_ptr())
+        assert torch.equal(f[v * per:(v + 1) * per], one), v
+    with pytest.raises(rtc.RtcError):
+        dw.render_views(cams + [rtc.camera(W, H + 8, 0.7)], 0, 1, f.data_ptr(), per)
+    with pytest.raises(rtc.RtcError):
+        dw.render_views(cams, 0, 1, f.data_ptr(), 8)        # view_rows too small
+    with pytest.raises(rtc.RtcError):
+        dw.render_views(cams * 2, 0, 1, f.data_ptr(), 200)  # more than 8 views
+    dw.close()
+
+
 def test_pinned_host_canvas(rtc, gpu, scenes):
     """rtc_host_alloc canvases: same pixels as the pageable path, reusable between frames, freed
     with the last view."""
