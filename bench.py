@@ -3,9 +3,11 @@
 
 Metric (BASELINE.json): Mrays/sec (primary+shadow), 1920x1080 x 100 spheres; 1/2/4/8 MI355X.
 A step = one frame: Camera::render_async over the synthetic N-sphere scene (SURVEY.md §8d,
-SplitMix64 seed 13) with the World and the Canvas tile resident in HBM. With --gpus N the frame
-is row-tiled (rank r renders rows [r*H/N, (r+1)*H/N)) and the tiles are gathered to rank 0 with
-one RCCL gather — total work is fixed, so scaling is "strong".
+SplitMix64 seed 13) with the World and the Canvas tile resident in HBM. One launch renders 8
+consecutive frames (rtc_render_views; --views-per-launch 1 makes a launch a frame). With --gpus N
+the frame is row-tiled (8-row bands dealt round-robin, rank r renders bands r, r+N, ...), the tiles
+of 32 frames are gathered to rank 0 with one RCCL gather and un-dealt there — total work is fixed,
+so scaling is "strong". DESIGN.md §6/§7 explain every one of these choices with measurements.
 
 Prints ONE JSON line on rank 0. `roofline` is the HBM view the north star asks for (algorithmic
 bytes / kernel time vs 8 TB/s). `valu_roofline` prices the reference's brute-force arithmetic
@@ -72,6 +74,12 @@ def parse():
                     help="single GPU: after the measured run, also time the same frames with two in flight on two HIP "
                          "streams and report it as the informational `pipelined` block (off by default so that a "
                          "profiler sees only the measured run's launches)")
+    ap.add_argument("--views-per-launch", type=int, default=0,
+                    help="how many consecutive frames one launch renders (rtc_render_views; every frame of this static "
+                         "benchmark has the same camera, an animation would pass its camera path). Default 8: the "
+                         "launch overheads, the ramp-up and the tail of a launch are paid once per 8 frames, and a "
+                         "rank's launch stays a whole frame's worth of work at 8 GPUs. 1 = a launch is a frame. "
+                         "Needs --tiling bands when the exchange is on")
     ap.add_argument("--time-every", type=int, default=0,
                     help="take the kernel duration on every n-th launch of each stream (a launch's start/stop events "
                          "cost ~9 us of host and ~5 us of GPU time). 0 = every launch on one GPU (what rocprofv3's "
@@ -89,14 +97,14 @@ def algorithmic_bytes(W, rows, world):
     return 24 * W * rows + 400 * n + 128 * n_pat + 200
 
 
-def measured_traffic(workload_prefix):
+def measured_traffic(workload_prefix, frames_per_launch=1):
     """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot be run
     from inside the timed process); newest summary whose workload matches, else None."""
     best = None
     for f in sorted((ROOT / "profiles").glob("r*_pmc.json")):
         try:
             d = json.loads(f.read_text())
-            if workload_prefix.startswith(d.get("workload", "\0")):
+            if workload_prefix.startswith(d.get("workload", "\0")) and d.get("frames_per_launch", 1) == frames_per_launch:
                 best = (d["hbm_traffic"]["traffic_bytes"], f"profiles/{f.name}")
         except Exception:
             continue
@@ -149,7 +157,12 @@ def main():
     world, cam = scenes.synthetic(args.spheres, W, H, with_plane=not args.no_plane, reflective=args.reflective)
     banded = args.tiling == "bands" and (world_size > 1 or args.force_dist)
     y0, y1 = tiles.row_range(H, world_size, rank)
-    rows_max = tiles.packed_rows(H, world_size) if banded else tiles.rows_per_rank(H, world_size)
+    V = args.views_per_launch if args.views_per_launch > 0 else (8 if (banded or not dist_on) else 1)
+    V = max(1, min(V, 8))
+    if V > 1 and dist_on and not banded:
+        sys.exit("--views-per-launch > 1 needs --tiling bands when the exchange is on")
+    rows_max = tiles.packed_rows(H, world_size) if (banded or V > 1) else tiles.rows_per_rank(H, world_size)
+    V = max(1, min(V, int(4e9 // (rows_max * W * 24))))     # a launch's V f64 tiles stay within ~4 GB (C5-sized frames: V = 2)
     rows_mine = (sum(min(8, H - 8 * b) for b in tiles.bands_of_rank(H, world_size, rank)) if banded else y1 - y0)
 
     # Stream 0 is torch's current stream (RCCL orders against it); further streams carry every S-th
@@ -171,9 +184,11 @@ def main():
     # frame: 20.4 us per frame at K = 8, 16.2 at 16, 14.3 at 32, 13.5 at 64, 12.9 without any exchange). Two batch buffers:
     # the RCCL gather of batch j runs (on RCCL's own stream) while batch j+1 renders; a buffer is reused
     # only after the gather that reads or fills it has completed.
-    K = max(1, args.frames_per_exchange) if dist_on else S   # frames in flight never share an output slot
+    K = max(1, args.frames_per_exchange) if dist_on else S * V   # frames in flight never share an output slot
     if dist_on:                     # a batch keeps K f64 tiles (+ their 8-bit frames) per buffer: stay within ~2 GB
         K = max(1, min(K, int(2e9 // (rows_max * W * 24))))
+        V = min(V, K)
+        K -= K % V                  # whole launches per batch
     nbuf = 1 if (not dist_on or args.no_overlap) else 2
     gdev = torch.device("cpu") if gloo else dev
     # every step renders the f64 canvas tile (resident in HBM, Canvas::get_pixel semantics) AND its
@@ -200,7 +215,8 @@ def main():
     # (the copy stays on the launch stream: a side stream would hide its few us of GPU time but costs
     # more than that in host calls, and at this frame size rank 0 is host-bound)
     pending = [None] * nbuf
-    state = {"k": 0}
+    state = {"k": 0, "pend": 0, "launches": 0}
+    cam_arrays = {n_: (type(cam) * n_)(*([cam] * n_)) for n_ in range(1, V + 1)}   # the frames' cameras, per launch size
 
     def step():
         k = state["k"]
@@ -211,12 +227,29 @@ def main():
                 finish(b)           # stream 0 waits for the gather that last used batch buffer b ...
             for st_ in streams[1:]:
                 st_.wait_stream(stream)   # ... and the other streams wait for stream 0 (once per batch)
-        lane = k % len(dworlds)
-        if not dist_on:
-            slot = lane             # single GPU: one output slot per stream (frames on one stream are ordered)
-        render_on(lane, tile_bufs[b][slot], tile8_bufs[b][slot])
+        state["pend"] += 1
+        if state["pend"] == V or slot == K - 1:
+            launch(b, slot)
         if dist_on and slot == K - 1:
             exchange(b)
+
+    def launch(b, last_slot):
+        """One launch for the frames accumulated since the last one (V of them, fewer at a batch's end)."""
+        cnt = state["pend"]
+        if cnt == 0:
+            return
+        state["pend"] = 0
+        lane = state["launches"] % len(dworlds)
+        state["launches"] += 1
+        # single GPU: every stream owns V output slots (frames on one stream are ordered); with the exchange
+        # on, a frame's slot is its place in the batch
+        first = last_slot - cnt + 1 if dist_on else lane * V
+        tile, tile8 = tile_bufs[b][first], tile8_bufs[b][first]
+        if V == 1:
+            render_on(lane, tile, tile8)
+        else:
+            dworlds[lane].render_views(cam_arrays[cnt], rank if banded else 0, world_size if banded else 1, tile.data_ptr(),
+                                       rows_max, rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
 
     def exchange(b):
         for st_ in streams[1:]:
@@ -282,9 +315,12 @@ def main():
     def drain():
         k = state["k"]
         state["last"] = k - 1
-        if dist_on and k % K != 0:  # a partly filled batch: exchange it as it is (the unused slots carry old frames)
-            exchange(((k - 1) // K) % nbuf)
-            state["k"] = k + (K - k % K)
+        if state["pend"]:            # frames handed to step() but not launched yet
+            launch(((k - 1) // K) % nbuf, (k - 1) % K)
+        if k % K != 0:              # a partly filled batch: exchange it as it is (the unused slots carry old frames)
+            if dist_on:
+                exchange(((k - 1) // K) % nbuf)
+            state["k"] = k + (K - k % K)   # the next frame starts a batch (and a launch)
         for b in range(nbuf):
             if pending[b] is not None:
                 finish(b)
@@ -297,6 +333,7 @@ def main():
         step()
     drain()
     time_every = args.time_every if args.time_every > 0 else (8 if dist_on else 1)
+    launches_before = state["launches"]
     for c in ctxs:
         c.reset_stats()
         c.set_timing(time_every)   # from here on: the timed region's launches only
@@ -376,13 +413,14 @@ def main():
         steps = max(1, args.steps)
         value = rays_ps / elapsed / 1e6
         rows = rows_mine
-        abytes = algorithmic_bytes(W, rows, world)
+        frames_per_launch = args.steps / max(1, state["launches"] - launches_before)   # V, or a little less if steps % V != 0
+        abytes = algorithmic_bytes(W, rows * frames_per_launch, world)   # per LAUNCH: that many frames' worth of this rank's rows, the scene once
         rays_rank = (st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"] + st["rays_refract"]) / steps
         hits_rank = st["rays_shadow"] / steps  # one shadow ray per shaded hit (shape.rs:688)
-        aflops = algorithmic_flops(world, rays_rank, hits_rank)
+        aflops = algorithmic_flops(world, rays_rank, hits_rank) * frames_per_launch     # per launch, like kernel_ms
         workload = (f"{W}x{H}, {args.spheres} spheres" + ("" if args.no_plane else " + checker floor plane") +
                     ", 1 point light, render_async, SplitMix64 seed 13" + (", reflective depth 5" if args.reflective else ""))
-        traffic = measured_traffic(workload) if world_size == 1 else None
+        traffic = measured_traffic(workload, V) if world_size == 1 else None
         out = {
             "metric": baseline_metric(),
             "value": round(value, 3),
@@ -398,7 +436,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": workload,
-                "objects": len(world), "rows_per_gpu": rows, "parallelism": (f"{'8-row bands dealt round-robin' if banded else 'contiguous row tiles'} x{world_size} + {'gloo (rehearsal)' if gloo else 'RCCL'} gather of the "
+                "objects": len(world), "rows_per_gpu": rows, "frames_per_launch": V, "parallelism": (f"{'8-row bands dealt round-robin' if banded else 'contiguous row tiles'} x{world_size} + {'gloo (rehearsal)' if gloo else 'RCCL'} gather of the "
                                                                           f"{'8-bit frame (Color::scale)' if args.gather == 'u8' else 'f64 canvas'} to rank 0"
                                                                           + (f", one gather per {K} frames" if K > 1 else "")
                                                                           + (f", {in_flight} frames in flight (HIP streams measured to run side by side)" if in_flight > 1 else "")
@@ -410,7 +448,7 @@ def main():
                 "bound": "hbm", "kernel": "k_trace", "achieved": round(abytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
                 "unit": "GB/s", "frac": round(abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
                 "traffic": int(traffic[0]) if traffic else None, "traffic_source": traffic[1] if traffic else None,
-                "algorithmic_bytes_per_launch": abytes, "kernel_ms_avg": round(kernel_ms, 5), "kernel_ms_last_launch": round(last_ms, 5),
+                "algorithmic_bytes_per_launch": int(abytes), "kernel_ms_avg": round(kernel_ms, 5), "kernel_ms_last_launch": round(last_ms, 5),
                 "kernel_launches_timed": int(len(times)), "kernel_timed_every": time_every,
                 "note": "one launch writes the f64 canvas tile once and reads the ~50 KB scene; the kernel is f64-VALU/latency bound, see DESIGN.md",
             },
