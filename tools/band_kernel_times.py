@@ -57,3 +57,25 @@ for N in (1, 2, 4, 8):
     for S in (2, 3, 4):
         line.append(f"S={S} {run([0] + order[:S - 1]):.4f}")
     print(f"N={N}: ms per frame of one rank, wall clock: " + ", ".join(line))
+
+# 8 frames per launch (rtc_render_views) of one rank's bands, on 1..3 streams
+cams8 = (type(cam) * 8)(*([cam] * 8))
+for N in (1, 2, 4, 8):
+    rows = tiles.packed_rows(H, N)
+    bufs = [(torch.zeros((8 * rows, W, 3), dtype=torch.float64, device="cuda:0"), torch.zeros((8 * rows, W, 3), dtype=torch.uint8, device="cuda:0")) for _ in range(len(dws))]
+
+    def run8(idx, reps=60):
+        best = 1e9
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for k in range(reps):
+                i = idx[k % len(idx)]
+                dws[i].render_views(cams8, 0, N, bufs[i][0].data_ptr(), rows, d_ptr8=bufs[i][1].data_ptr())
+            torch.cuda.synchronize()
+            best = min(best, (time.perf_counter() - t) / (reps * 8))
+        return best * 1e3
+
+    base = run8([0])
+    order = sorted(range(1, len(dws)), key=lambda j: run8([0, j], 20))
+    print(f"N={N}: ms per frame of one rank with 8 frames per launch: S=1 {base:.4f}, S=2 {run8([0] + order[:1]):.4f}, S=3 {run8([0] + order[:2]):.4f}")
