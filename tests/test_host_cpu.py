@@ -283,3 +283,23 @@ def test_oracle_threads_and_row_ranges_agree(O, rtc, scenes):
     assert np.array_equal(full, O.render(arr, len(w), w.light, cam, mode=1, nthreads=5))
     part = O.render(arr, len(w), w.light, cam, mode=1, y0=10, y1=23, nthreads=3)
     assert np.array_equal(part, full[10:23])
+
+
+def test_loader_and_writers_under_address_and_ub_sanitizers(tmp_path):
+    """The host-only sources (scene loader, matrix helpers, PPM / RGBA8 writers) built with
+    -fsanitize=address,undefined and driven by tests/cpp/test_loader_asan.cpp: the shipped scene, every
+    truncation of it, malformed documents, a 3000-object document. (Sanitizers run on the CPU build
+    only; the GPU pool does not offer them.)"""
+    import shutil
+    import subprocess
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    csrc = ROOT / "raytracer-challenge_amd" / "csrc"
+    exe = tmp_path / "test_loader_asan"
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+           "-ffp-contract=off", f"-I{ROOT / 'include'}", f"-I{csrc}", str(ROOT / "tests" / "cpp" / "test_loader_asan.cpp"),
+           str(csrc / "host_yaml.cpp"), str(csrc / "host_math.cpp"), str(csrc / "host_ppm.cpp"), "-o", str(exe)]
+    subprocess.run(cmd, check=True, timeout=300)
+    r = subprocess.run([str(exe), str(ROOT / "raytracer-challenge_amd" / "data" / "reflect_refract.yml")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    assert "no crash" in r.stdout
