@@ -68,8 +68,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=0,
                     help="frames in flight: consecutive frames are launched round-robin on this many HIP streams, so a "
                          "launch that cannot fill the chip (a rank's 1/N of the frame) overlaps the next one. "
-                         "0 = 1 stream for the single-GPU run (clean per-kernel timing), up to 3 for N > 1 "
-                         "(as many as are measured to run side by side)")
+                         "0 = 1 stream for the single-GPU run (clean per-kernel timing), 2 for N > 1 "
+                         "(if two are measured to run side by side)")
     ap.add_argument("--pipelined-probe", action="store_true",
                     help="single GPU: after the measured run, also time the same frames with two in flight on two HIP "
                          "streams and report it as the informational `pipelined` block (off by default so that a "
@@ -168,7 +168,7 @@ def main():
     # Stream 0 is torch's current stream (RCCL orders against it); further streams carry every S-th
     # frame. One context (= one stream, one event ring, one counter block) per stream, the World uploaded
     # into each (it is ~50 KB).
-    S = args.streams if args.streams > 0 else (3 if dist_on else 1)
+    S = args.streams if args.streams > 0 else (2 if dist_on else 1)
     stream = torch.cuda.current_stream(dev)
     # HIP multiplexes streams onto 4 hardware queues (GPU_MAX_HW_QUEUES; raising it made things slower
     # here): a second render stream easily lands on the queue of the first and the two then serialise.
