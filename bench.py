@@ -212,8 +212,6 @@ def main():
         else:        # (N, K, rows) -> (K, N, rows)
             undeal = [(f.view(K, world_size, rows_max, W, 3), c.view(world_size, K, rows_max, W, 3).permute(1, 0, 2, 3, 4))
                       for c, f in zip(canvases, frames)]
-    # (the copy stays on the launch stream: a side stream would hide its few us of GPU time but costs
-    # more than that in host calls, and at this frame size rank 0 is host-bound)
     pending = [None] * nbuf
     state = {"k": 0, "pend": 0, "launches": 0}
     cam_arrays = {n_: (type(cam) * n_)(*([cam] * n_)) for n_ in range(1, V + 1)}   # the frames' cameras, per launch size
@@ -251,9 +249,16 @@ def main():
             dworlds[lane].render_views(cam_arrays[cnt], rank if banded else 0, world_size if banded else 1, tile.data_ptr(),
                                        rows_max, rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
 
+    # rank 0's un-deal copy (a batch's worth of frames, read + written once) runs on its own stream so that
+    # rank 0's renders do not queue behind it: it depends on the gather only. (Per batch, not per frame: the
+    # extra host calls no longer matter.)
+    copy_stream = torch.cuda.Stream(dev) if (need_copy and not gloo) else None
+
     def exchange(b):
         for st_ in streams[1:]:
             stream.wait_stream(st_)       # the gather (ordered after stream 0) needs every frame of the batch
+        if copy_stream is not None:
+            stream.wait_stream(copy_stream)   # ... and overwrites canvases[b]: its last un-deal copy must be done
         src = (tile8_bufs[b] if args.gather == "u8" else tile_bufs[b]).view(K * rows_max, W, 3)
         src = src.cpu() if gloo else src
         work = tiles.gather_tiles(src, canvases[b], world_size, rank, async_op=not args.no_overlap, bands=bands[b])
@@ -264,9 +269,14 @@ def main():
 
     def finish(b):
         work, pending[b] = pending[b], None
-        work.wait()
+        work.wait()                       # stream 0: the batch's tile buffer is rendered into next
         if need_copy:
-            undeal[b][0].copy_(undeal[b][1])
+            if copy_stream is not None:
+                with torch.cuda.stream(copy_stream):
+                    work.wait()
+                    undeal[b][0].copy_(undeal[b][1])
+            else:
+                undeal[b][0].copy_(undeal[b][1])
 
     def render_on(i, tile, tile8):
         if banded:
