@@ -522,8 +522,29 @@ def cpu_baseline(world, cam, budget_s):
         dt = time.perf_counter() - t
         rays = st["rays_primary"] + st["rays_shadow"]
         sample = f"rows [{ya},{ya + rows}) of {cam.hsize}x{cam.vsize} (centre band)"
-    return {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample,
-            "seconds": round(dt, 2), "form": "literal sorted-list oracle (oracle/rtc_oracle.c), f64, -O2 -ffp-contract=off"}
+    out = {"value": round(rays / dt / 1e6, 4), "unit": "Mrays/s", "cores": cores, "kind": "port", "sample": sample,
+           "seconds": round(dt, 2), "form": "literal sorted-list oracle (oracle/rtc_oracle.c), f64, -O2 -ffp-contract=off"}
+
+    # BASELINE.md §3's two other variants, on small bounded samples (a band of rows each, ~2 s):
+    # the literal form on ONE thread (analogue of Camera::render) and the streaming form on all cores
+    def band_rate(nthreads, streaming, seconds):
+        rows = max(1, int(H * seconds / max(est_frame * (cores / nthreads if not streaming else 1.0), 1e-6)))
+        rows = min(rows, H)
+        ya = (H - rows) // 2
+        t = time.perf_counter()
+        rays_, reps = 0, 0
+        while reps == 0 or (rows == H and time.perf_counter() - t < seconds):   # whole frames: repeat until the time is used
+            _, st_ = O.render(arr, len(world), world.light, cam, mode=1, y0=ya, y1=ya + rows, nthreads=nthreads, streaming=streaming,
+                              want_stats=True)
+            rays_ += st_["rays_primary"] + st_["rays_shadow"]
+            reps += 1
+        d = time.perf_counter() - t
+        return {"value": round(rays_ / d / 1e6, 4), "unit": "Mrays/s", "cores": nthreads,
+                "sample": (f"{reps} full frame(s)" if rows == H else f"rows [{ya},{ya + rows}) of {cam.hsize}x{cam.vsize}"), "seconds": round(d, 2)}
+
+    out["literal_1_thread"] = band_rate(1, False, 2.0)
+    out["streaming_all_cores"] = band_rate(cores, True, 2.0)
+    return out
 
 
 if __name__ == "__main__":
