@@ -1,6 +1,6 @@
 """One-off stress campaign (not part of the test suite): many random adversarial worlds, the culled
 kernels (one- and two-level) against plain brute force on the GPU, bit for bit (canvas + ray counts);
-every 10th world also against the CPU oracle. Usage: python tools/stress_parity.py [n_worlds] [seed0]"""
+every 10th world also against the CPU oracle. Usage: python tests/stress_parity.py [n_worlds] [seed0]"""
 import importlib
 import os
 import sys

@@ -273,7 +273,7 @@ def test_cull_is_exact_on_adversarial_scenes(rtc, gpu, O):
 
 @pytest.mark.parametrize("seed", [701683, 755117])
 def test_cull_regressions_found_by_the_stress_campaign(rtc, gpu, O, seed):
-    """Two worlds out of ~85 000 random ones (tools/stress_parity.py) once differed from brute force:
+    """Two worlds out of ~85 000 random ones (tests/stress_parity.py) once differed from brute force:
     701683 — a wide shadow bundle whose sine had been inflated independently of its cosine;
     755117 — a shadow ray starting 1.1e6 units away that the REFERENCE arithmetic reports as hitting
     a thin ellipsoid it geometrically misses by two radii (catastrophic cancellation in b*b - 4ac):
