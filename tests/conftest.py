@@ -27,6 +27,12 @@ def rtc():
     """The product package (ctypes binding of librtc.so)."""
     from _bootstrap import package
     pkg = package()
+    if not pkg.LIB_PATH.exists():   # a checkout that was never built: compile librtc.so (hipcc cross-compiles gfx950)
+        import importlib.util
+        spec = importlib.util.spec_from_file_location("_rtc_build", ROOT / "raytracer-challenge_amd" / "build.py")
+        b = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(b)
+        b.build()
     pkg.lib()
     return pkg
 
