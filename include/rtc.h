@@ -297,11 +297,11 @@ void        rtc_host_free(void *p);
 /* Ray counters accumulated since the last reset (synchronises the stream). */
 rtc_status  rtc_stats_read(rtc_context *ctx, rtc_stats *out);
 rtc_status  rtc_stats_reset(rtc_context *ctx);
-/* Kernel timing. Every rtc_render_rows launch carries its own pair of HIP events that receive
+/* Kernel timing. Every render launch (rtc_render_rows / _bands / _views) carries its own pair of HIP events that receive
  * the dispatch's begin and end timestamps on the context stream (hipExtLaunchKernel: no marker
  * packets, the same quantity rocprofv3's kernel trace reports) unless rtc_context_set_timing says
- * otherwise. The context keeps the most recent 1024 pairs. rtc_kernel_times_ms writes the durations (ms) of the latest min(cap, kept)
- * launches, oldest first, and their number to *n; rtc_last_kernel_ms is the newest one alone
+ * otherwise. The context keeps the most recent 1024 pairs. rtc_kernel_times_ms writes the
+ * durations (ms) of the latest min(cap, kept) launches, oldest first, and their number to *n; rtc_last_kernel_ms is the newest one alone
  * (RTC_ERR_ARG if nothing was launched yet). Both wait for the newest launch to finish. */
 rtc_status  rtc_kernel_times_ms(rtc_context *ctx, float *out, uint32_t cap, uint32_t *n);
 /* Which launches carry an event pair: every `every`-th one (1 = all, the default; 0 = none). The
