@@ -517,7 +517,8 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     P.counters = ctx->d_counters;
     P.rays = nullptr;
     P.remaining = RTC_MAX_REFLECTIONS; // render_pixel passes Camera::MAX_REFLECTIONS camera.rs:98
-    P.grid_x = (cam->hsize + 31u) / 32u;
+    const uint32_t tile_w = RTC_TILE_W_OF(w->any_refl || w->any_refr);
+    P.grid_x = (cam->hsize + tile_w - 1u) / tile_w;
     P.grid_y = grid_y;
     P.band_stride = band_stride;
     int src;
@@ -726,7 +727,8 @@ rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays
         P.nrays = n;
         P.remaining = remaining;
         P.hits = d_hits;
-        P.grid_x = (n + 255u) / 256u;
+        const uint32_t blk = RTC_BLOCK_OF(w->any_refl || w->any_refr);
+        P.grid_x = (n + blk - 1u) / blk;
         P.grid_y = 1;
         P.band_stride = 1;
         int src;

@@ -29,7 +29,6 @@
 #include "rtc.h"
 #include "rtc_device.h"
 
-#define RTC_BLOCK 256
 #define RTC_MAX_STACK 8
 // Tile output: true = each wave stores its own 8x8 part as soon as it is done, false = workgroup
 // barrier + cooperative store of the whole 32x8 tile (full 128-byte lines). Measured: the barrier
@@ -553,10 +552,10 @@ DEVI LdsView lds_view(double *base, uint32_t cap) {
 
 DEVI void stage_tile(const Tables &T, const LdsView &L, uint32_t base, uint32_t cnt) {
     const double *gm = reinterpret_cast<const double *>(T.isect + base);
-    for (uint32_t e = threadIdx.x; e < cnt * 12; e += RTC_BLOCK) L.m[e] = gm[e];
+    for (uint32_t e = threadIdx.x; e < cnt * 12; e += blockDim.x) L.m[e] = gm[e];
     const double *gp = reinterpret_cast<const double *>(T.prim + base);
-    for (uint32_t e = threadIdx.x; e < cnt * 4; e += RTC_BLOCK) L.prim[e] = gp[e];
-    for (uint32_t e = threadIdx.x; e < cnt; e += RTC_BLOCK) L.kind[e] = T.kind[base + e];
+    for (uint32_t e = threadIdx.x; e < cnt * 4; e += blockDim.x) L.prim[e] = gp[e];
+    for (uint32_t e = threadIdx.x; e < cnt; e += blockDim.x) L.kind[e] = T.kind[base + e];
 }
 
 // Skip (two-level cull, closest-hit passes of rays that start at the bundle's apex with unit
@@ -816,14 +815,15 @@ DEVI V3 combine(V3 surface, V3 reflected, V3 refracted, bool schlick, double R) 
 // PROBE = true is the rtc_color_at flavour (arbitrary rays in, colours + hit records out); the
 // render flavour (PROBE = false) never carries the hit record's extra vectors in registers.
 template <int SRC, bool REFL, bool REFR, bool PROBE>
-__global__ void __launch_bounds__(RTC_BLOCK, (REFL ? RTC_WAVES_PER_SIMD_STACK : RTC_WAVES_PER_SIMD))
+__global__ void __launch_bounds__(RTC_BLOCK_OF(REFL), (REFL ? RTC_WAVES_PER_SIMD_STACK : RTC_WAVES_PER_SIMD))
 k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const uint32_t *__restrict__ t_kind,
         const DevShade *__restrict__ t_shade, const DevPrim *__restrict__ t_prim, const DevBound *__restrict__ t_bound,
         const DevIsect *__restrict__ t_isect_s, const uint32_t *__restrict__ t_kind_s, const DevBound *__restrict__ t_bound_s,
         const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound) {
+    constexpr uint32_t BLOCK = RTC_BLOCK_OF(REFL), TILE_W = RTC_TILE_W_OF(REFL);
     extern __shared__ double lds_raw[];
-    __shared__ __attribute__((aligned(16))) double stage_f64[PROBE ? 1 : 8 * 32 * 3];      // the tile, canvas layout
-    __shared__ __attribute__((aligned(16))) unsigned char stage_u8[PROBE ? 16 : 8 * 32 * 3];
+    __shared__ __attribute__((aligned(16))) double stage_f64[PROBE ? 1 : 8 * TILE_W * 3];      // the tile, canvas layout
+    __shared__ __attribute__((aligned(16))) unsigned char stage_u8[PROBE ? 16 : 8 * TILE_W * 3];
     const auto &P = KP(P_arg); // set-up view: grid, sizes, mode
     const LdsView L = lds_view(lds_raw, P.tile_cap);
     Tables T;
@@ -849,14 +849,14 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     uint32_t view = 0, tbid = bid; // which camera of the launch, and the tile's index inside that view
     bool in_range, traced;
     if (probe) {
-        ray_index = bid * RTC_BLOCK + threadIdx.x;
+        ray_index = bid * BLOCK + threadIdx.x;
         in_range = ray_index < P.nrays;
         traced = in_range;
     } else {
         const uint32_t tiles = P.grid_x * P.grid_y;
         if (P.nviews > 1u) { view = bid / tiles; tbid = bid % tiles; }
         const uint32_t bx = tbid % P.grid_x, by = tbid / P.grid_x;
-        px = bx * 32u + wave * 8u + (lane & 7u);
+        px = bx * TILE_W + wave * 8u + (lane & 7u);
         py = P.y0 + by * P.band_stride * 8u + (lane >> 3);
         in_range = px < P.W && py < P.y1;
         // Camera::render leaves the last row and column untouched (camera.rs:120-121)
@@ -1232,7 +1232,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             // Between AA samples the LDS slot also holds Color::average_over's running sums
             // (color.rs:128-139: reds = ((0 + c0) + c1) + ...).
             const uint32_t tx = wave * 8u + (lane & 7u), ty = lane >> 3; // position inside the tile
-            double *slot = stage_f64 + (ty * 32u + tx) * 3u;
+            double *slot = stage_f64 + (ty * TILE_W + tx) * 3u;
             if (!traced) result = mk(0., 0., 0.); // Canvas::new BLACK canvas.rs:37-41
             if (nsamples > 1u) {
                 V3 acc = (s == 0u) ? mk(0., 0., 0.) : mk(slot[0], slot[1], slot[2]);
@@ -1250,7 +1250,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 const auto &Po = KP(P_arg); // output view
                 const bool want8 = Po.out8 != nullptr;
                 if (want8) {
-                    unsigned char *q = stage_u8 + (ty * 32u + tx) * 3u;
+                    unsigned char *q = stage_u8 + (ty * TILE_W + tx) * 3u;
                     q[0] = scale255(result.x);
                     q[1] = scale255(result.y);
                     q[2] = scale255(result.z);
@@ -1263,7 +1263,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t px0 = (tbid % Po.grid_x) * 32u + wave * 8u, py0 = Po.y0 + (tbid / Po.grid_x) * Po.band_stride * 8u,
+                const uint32_t px0 = (tbid % Po.grid_x) * TILE_W + wave * 8u, py0 = Po.y0 + (tbid / Po.grid_x) * Po.band_stride * 8u,
                                orow0 = view * Po.view_rows + (tbid / Po.grid_x) * 8u; // first image row / first output row of the tile
                 const uint32_t cols = (px0 >= Po.W) ? 0u : ((Po.W - px0 < 8u) ? (Po.W - px0) : 8u); // valid pixels per row
                 const uint32_t rows = (Po.y1 - py0 < 8u) ? (Po.y1 - py0) : 8u;                       // valid tile rows
@@ -1275,14 +1275,14 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     typedef double __attribute__((ext_vector_type(2))) d2;
                     for (uint32_t c = lane; c < rows * 12u; c += 64u) {
                         const uint32_t r = c / 12u, k = c % 12u;
-                        const d2 v = *reinterpret_cast<const d2 *>(src + r * 96u + k * 2u);
+                        const d2 v = *reinterpret_cast<const d2 *>(src + r * (TILE_W * 3u) + k * 2u);
                         char *dst = reinterpret_cast<char *>(Po.out) + (size_t)(orow0 + r) * row_bytes + (size_t)px0 * 24u + k * 16u;
                         *reinterpret_cast<d2 *>(dst) = v;
                     }
                 } else {
                     for (uint32_t c = lane; c < rows * cols * 3u; c += 64u) {
                         const uint32_t r = c / (cols * 3u), k = c % (cols * 3u);
-                        Po.out[((size_t)(orow0 + r) * Po.W + px0) * 3u + k] = src[r * 96u + k];
+                        Po.out[((size_t)(orow0 + r) * Po.W + px0) * 3u + k] = src[r * (TILE_W * 3u) + k];
                     }
                 }
                 if (want8) {
@@ -1294,53 +1294,53 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                         typedef unsigned __attribute__((ext_vector_type(2))) u2;
                         for (uint32_t c = lane; c < rows * 3u; c += 64u) {
                             const uint32_t r = c / 3u, k = c % 3u;
-                            const u2 v = *reinterpret_cast<const u2 *>(src8 + r * 96u + k * 8u);
+                            const u2 v = *reinterpret_cast<const u2 *>(src8 + r * (TILE_W * 3u) + k * 8u);
                             *reinterpret_cast<u2 *>(Po.out8 + (size_t)(orow0 + r) * row8 + (size_t)px0 * 3u + k * 8u) = v;
                         }
                     } else {
                         for (uint32_t c = lane; c < rows * cols * 3u; c += 64u) {
                             const uint32_t r = c / (cols * 3u), k = c % (cols * 3u);
-                            Po.out8[((size_t)(orow0 + r) * Po.W + px0) * 3u + k] = src8[r * 96u + k];
+                            Po.out8[((size_t)(orow0 + r) * Po.W + px0) * 3u + k] = src8[r * (TILE_W * 3u) + k];
                         }
                     }
                 }
                 } else {
                 __syncthreads();
-                const uint32_t px0 = (tbid % Po.grid_x) * 32u, py0 = Po.y0 + (tbid / Po.grid_x) * Po.band_stride * 8u,
+                const uint32_t px0 = (tbid % Po.grid_x) * TILE_W, py0 = Po.y0 + (tbid / Po.grid_x) * Po.band_stride * 8u,
                                orow0 = view * Po.view_rows + (tbid / Po.grid_x) * 8u; // first image row / first output row of the tile
-                const uint32_t cols = (Po.W - px0 < 32u) ? (Po.W - px0) : 32u;      // valid pixels per tile row
+                const uint32_t cols = (Po.W - px0 < TILE_W) ? (Po.W - px0) : TILE_W;      // valid pixels per tile row
                 const uint32_t rows = (Po.y1 - py0 < 8u) ? (Po.y1 - py0) : 8u;      // valid tile rows
                 // f64 canvas: 16-byte pieces when every tile row is whole and 16-byte aligned
                 const size_t row_bytes = (size_t)Po.W * 24u;
-                const bool wide = cols == 32u && (row_bytes % 16u) == 0 && ((size_t)Po.out % 16u) == 0;
+                const bool wide = cols == TILE_W && (row_bytes % 16u) == 0 && ((size_t)Po.out % 16u) == 0;
                 if (wide) {
                     typedef double __attribute__((ext_vector_type(2))) d2;
-                    for (uint32_t c = threadIdx.x; c < rows * 48u; c += RTC_BLOCK) {
-                        const uint32_t r = c / 48u, k = c % 48u;
-                        const d2 v = *reinterpret_cast<const d2 *>(stage_f64 + r * 96u + k * 2u);
+                    for (uint32_t c = threadIdx.x; c < rows * (TILE_W * 3u / 2u); c += BLOCK) {
+                        const uint32_t r = c / (TILE_W * 3u / 2u), k = c % (TILE_W * 3u / 2u);
+                        const d2 v = *reinterpret_cast<const d2 *>(stage_f64 + r * (TILE_W * 3u) + k * 2u);
                         char *dst = reinterpret_cast<char *>(Po.out) + (size_t)(orow0 + r) * row_bytes + (size_t)px0 * 24u + k * 16u;
                         *reinterpret_cast<d2 *>(dst) = v;
                     }
                 } else {
-                    for (uint32_t c = threadIdx.x; c < rows * cols * 3u; c += RTC_BLOCK) {
+                    for (uint32_t c = threadIdx.x; c < rows * cols * 3u; c += BLOCK) {
                         const uint32_t r = c / (cols * 3u), k = c % (cols * 3u);
-                        Po.out[((size_t)(orow0 + r) * Po.W + px0) * 3u + k] = stage_f64[r * 96u + k];
+                        Po.out[((size_t)(orow0 + r) * Po.W + px0) * 3u + k] = stage_f64[r * (TILE_W * 3u) + k];
                     }
                 }
                 if (want8) {
                     const size_t row8 = (size_t)Po.W * 3u;
-                    const bool wide8 = cols == 32u && (row8 % 16u) == 0 && ((size_t)Po.out8 % 16u) == 0;
+                    const bool wide8 = cols == TILE_W && (row8 % 16u) == 0 && ((size_t)Po.out8 % 16u) == 0;
                     if (wide8) {
                         typedef unsigned __attribute__((ext_vector_type(4))) u4;
-                        for (uint32_t c = threadIdx.x; c < rows * 6u; c += RTC_BLOCK) {
-                            const uint32_t r = c / 6u, k = c % 6u;
-                            const u4 v = *reinterpret_cast<const u4 *>(stage_u8 + r * 96u + k * 16u);
+                        for (uint32_t c = threadIdx.x; c < rows * (TILE_W * 3u / 16u); c += BLOCK) {
+                            const uint32_t r = c / (TILE_W * 3u / 16u), k = c % (TILE_W * 3u / 16u);
+                            const u4 v = *reinterpret_cast<const u4 *>(stage_u8 + r * (TILE_W * 3u) + k * 16u);
                             *reinterpret_cast<u4 *>(Po.out8 + (size_t)(orow0 + r) * row8 + (size_t)px0 * 3u + k * 16u) = v;
                         }
                     } else {
-                        for (uint32_t c = threadIdx.x; c < rows * cols * 3u; c += RTC_BLOCK) {
+                        for (uint32_t c = threadIdx.x; c < rows * cols * 3u; c += BLOCK) {
                             const uint32_t r = c / (cols * 3u), k = c % (cols * 3u);
-                            Po.out8[((size_t)(orow0 + r) * Po.W + px0) * 3u + k] = stage_u8[r * 96u + k];
+                            Po.out8[((size_t)(orow0 + r) * Po.W + px0) * 3u + k] = stage_u8[r * (TILE_W * 3u) + k];
                         }
                     }
                 }
@@ -1354,7 +1354,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     if (Pc.counters) {
         const uint32_t npix = popc64(ballot(traced));
         if (lane == 0) {
-            unsigned long long *slot = Pc.counters + (size_t)((blockIdx.x * 4u + wave) % CNT_SLOTS) * CNT_N;
+            unsigned long long *slot = Pc.counters + (size_t)((blockIdx.x * (BLOCK / 64u) + wave) % CNT_SLOTS) * CNT_N;
             if (c_primary) atomicAdd(slot + CNT_PRIMARY, (unsigned long long)c_primary);
             if (c_shadow) atomicAdd(slot + CNT_SHADOW, (unsigned long long)c_shadow);
             if (c_reflect) atomicAdd(slot + CNT_REFLECT, (unsigned long long)c_reflect);
@@ -1370,11 +1370,11 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
 
 // Per-render prologue: camera origin in each object's space and the sphere quadratic's `c`
 // (shape.rs:363,366) — the part of every primary-ray test that does not depend on the pixel.
-__global__ void __launch_bounds__(RTC_BLOCK) k_prep_primary(const DevIsect *isect, DevPrim *prim, uint32_t n,
+__global__ void __launch_bounds__(256) k_prep_primary(const DevIsect *isect, DevPrim *prim, uint32_t n,
                                                             double v0, double v1, double v2, double v3, double v4,
                                                             double v5, double v6, double v7, double v8, double v9,
                                                             double v10, double v11) {
-    const uint32_t j = blockIdx.x * RTC_BLOCK + threadIdx.x;
+    const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= n) return;
     const double vinv[12] = {v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11};
     const V3 origin = xpoint(vinv, mk(0., 0., 0.));
@@ -1410,7 +1410,7 @@ static hipError_t launch_kernel(const RenderParams &P, dim3 grid, size_t lds_byt
         if (e != hipSuccess) return e;
     }
     // e0/e1 (may be NULL) receive the dispatch's own begin/end timestamps: no marker packets on the stream
-    hipExtLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK), lds_bytes, stream, e0, e1, 0, P, P.isect,
+    hipExtLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK_OF(REFL)), lds_bytes, stream, e0, e1, 0, P, P.isect,
                           P.kind, P.shade, P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound);
     return hipGetLastError();
 }
@@ -1442,7 +1442,7 @@ extern "C" hipError_t rtc_launch_trace(const RenderParams *P, int src, int refl,
 extern "C" hipError_t rtc_launch_prep(const DevIsect *isect, DevPrim *prim, uint32_t n, const double vinv[12],
                                       hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_prep_primary, dim3((n + RTC_BLOCK - 1) / RTC_BLOCK), dim3(RTC_BLOCK), 0, stream, isect, prim,
+    hipLaunchKernelGGL(k_prep_primary, dim3((n + 255u) / 256u), dim3(256), 0, stream, isect, prim,
                        n, vinv[0], vinv[1], vinv[2], vinv[3], vinv[4], vinv[5], vinv[6], vinv[7], vinv[8], vinv[9],
                        vinv[10], vinv[11]);
     return hipGetLastError();
