@@ -73,13 +73,14 @@ struct DevCamera {
 enum { RTC_MAX_VIEWS = 8 };
 
 // Workgroup = waves side by side, each an 8x8 pixel tile: the workgroup's tile is (threads/64)*8 x 8
-// pixels (host grid and kernel must agree). The flat kernel uses 256 threads (its workgroup stores the
-// tile cooperatively in full 128-byte lines; 128 is the same speed, 512 is 16 % slower); the
+// pixels (host grid and kernel must agree). The flat kernel uses 128 threads (its workgroup stores the
+// 16x8 tile cooperatively, three full 128-byte lines per row; against 256 threads: the same at 100
+// objects, 5 % faster at 1000 and 10 000; 64 is within 2 % either way, 512 is 16 % slower); the
 // frame-stack kernels, whose waves finish far apart and store their parts on their own, use ONE wave per
 // workgroup — a workgroup's slots are only handed on when its last wave is done (reflective 1080p:
 // 256 threads 0.535 ms, 128 0.475, 64 0.463; 4096x4096: 2.27 / 1.82 / 1.63 ms).
 #ifndef RTC_BLOCK
-#define RTC_BLOCK 256
+#define RTC_BLOCK 128
 #endif
 #ifndef RTC_BLOCK_STACK
 #define RTC_BLOCK_STACK 64

@@ -5,7 +5,8 @@
 //
 // Design:
 //  * one thread per pixel; a wave owns an 8x8 pixel tile (coherent hit / miss / shadow
-//    decisions), a 256-thread workgroup a 32x8 tile; tile = workgroup id, which the hardware
+//    decisions), a workgroup 2 such tiles side by side (1 for the frame-stack kernels, rtc_device.h);
+//    tile = workgroup id, which the hardware
 //    deals round-robin over the 8 XCDs (an even share of the image for each, RTC_TILE_ORDER).
 //  * every value is IEEE f64 evaluated in the reference's operation order; the file is
 //    compiled with -ffp-contract=off, so results are bit-identical to the CPU path apart
@@ -31,7 +32,7 @@
 
 #define RTC_MAX_STACK 8
 // Tile output: true = each wave stores its own 8x8 part as soon as it is done, false = workgroup
-// barrier + cooperative store of the whole 32x8 tile (full 128-byte lines). Measured: the barrier
+// barrier + cooperative store of the workgroup's whole tile (full 128-byte lines). Measured: the barrier
 // form wins for the flat kernel (0.0738 vs 0.0784 ms, 192-byte row pieces straddle lines), the
 // per-wave form for the frame-stack kernels, whose waves finish far apart (0.662 vs 0.690 ms).
 #ifndef RTC_WAVE_OUTPUT
@@ -1224,9 +1225,9 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 o[2] = result.z;
             }
         } else {
-            // The workgroup's 32x8 pixel tile is staged in LDS (row-major, exactly the canvas layout of
-            // the tile) and written out by the whole workgroup: each tile row is 768 contiguous bytes
-            // of the f64 canvas (six full 128-byte lines) and 96 contiguous bytes of the 8-bit frame,
+            // The workgroup's (TILE_W x 8)-pixel tile is staged in LDS (row-major, exactly the canvas layout of
+            // the tile) and written out by the whole workgroup: with TILE_W = 16 each tile row is 384 contiguous
+            // bytes of the f64 canvas (three full 128-byte lines) and 48 contiguous bytes of the 8-bit frame,
             // stored 16 bytes per lane. Direct per-pixel stores (3 x 8 B at a 24 B stride, 3 single
             // bytes) cost 1.6x the algorithmic bytes in HBM write traffic (rocprofv3 WRITE_SIZE).
             // Between AA samples the LDS slot also holds Color::average_over's running sums
