@@ -63,7 +63,8 @@
 #endif
 // 2nd argument of __launch_bounds__ = minimum waves per SIMD (caps VGPRs: 5 -> 96, 4 -> 128,
 // 3 -> 168, 2 -> 256). Measured on the north-star scene (culled flat kernel, 90 VGPRs):
-// 4 -> 0.0784 ms, 5 -> 0.0736 ms, 6 -> 0.0882 ms.
+// 4 -> 0.0784 ms, 5 -> 0.0736 ms, 6 -> 0.0882 ms with 256-thread workgroups and one frame per launch; with
+// 128-thread workgroups and 8 frames per launch 4, 5 and 6 measure the same (0.5365 ms per launch).
 // Kernels that carry the reflection/refraction frame stack: see RTC_WAVES_PER_SIMD_STACK.
 #ifndef RTC_WAVES_PER_SIMD
 #define RTC_WAVES_PER_SIMD 5
