@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 1u
+#define RTC_ABI_VERSION 2u
 
 /* ---- status codes (the reference panics instead) -------------------- */
 typedef int32_t rtc_status;
@@ -45,7 +45,7 @@ enum {
     RTC_ERR_PARSE      = 5, /* scene description rejected (lua.rs:216,322-326 analogue)         */
     RTC_ERR_IO         = 6, /* file could not be opened / written     canvas.rs:87-91           */
     RTC_ERR_NOMEM      = 7,
-    RTC_ERR_UNSUPPORTED= 8  /* e.g. randomised AA resample (camera.rs:84-92), see rtc_camera    */
+    RTC_ERR_UNSUPPORTED= 8  /* a build or device without what the call needs (e.g. no RCCL library)   */
 };
 
 /* ---- enumerations ------------------------------------------------------------------ */
@@ -74,7 +74,11 @@ enum { /* render flags (bit set) */
     RTC_FLAG_NO_CULL   = 1u << 0, /* visit every object for every ray (plain brute force); the
                                      default culls objects with a conservative bound first and
                                      produces bit-identical results */
-    RTC_FLAG_RESERVED1 = 1u << 1
+    RTC_FLAG_AA_RESAMPLE = 1u << 1, /* antialiasing_samples > 1 only: take render_pixel's adaptive resample branch
+                                     (camera.rs:84-92,108-111) on the device, with the counter-based offsets
+                                     documented at rtc_camera.samples (the reference draws them from thread_rng).
+                                     Without this flag such pixels keep the mean of the 4 fixed sub-samples and are
+                                     COUNTED in rtc_stats.pixels_resample, so the caller knows how many differ.      */
 };
 
 #define RTC_MAX_REFLECTIONS 5u /* Camera::MAX_REFLECTIONS camera.rs:31 */
@@ -104,7 +108,14 @@ typedef struct rtc_material {
 typedef struct rtc_shape {
     uint32_t     kind;       /* RTC_SPHERE / RTC_PLANE / RTC_CUBE                           */
     uint32_t     world_id;   /* World::add_shape assigns last_world_id+1 (shape.rs:661-667);
-                                only compared for equality (shape.rs:127)                   */
+                                only compared for equality (shape.rs:127). rtc_world_create
+                                numbers the shapes 1..n itself when EVERY id is 0 (what
+                                rtc_shape_init leaves), and otherwise honours the ids given:
+                                two shapes with the same id are one "container" to
+                                compute_refractive, exactly as in the reference. The
+                                reference's own ids are u8 and wrap at 256 shapes
+                                (shape.rs:287): a caller that passes `get_world_id()` as
+                                it is reproduces that domain too.                           */
     double       inv[16];
     double       inv_t[16];
     rtc_material material;
@@ -122,11 +133,26 @@ typedef struct rtc_camera {
     double   fov;
     double   half_width, half_height, pixel_size;
     double   view_inv[16];   /* view_transform_inv: inverse of the view matrix camera.rs:35 */
-    uint32_t samples;        /* antialiasing_samples (camera.rs:24). 1 = one ray per pixel.
-                                >1 = the 4 fixed sub-samples of render_pixel
-                                (camera.rs:101-107) averaged; the thread_rng resample branch
-                                (camera.rs:84-92,109-111) is non-deterministic in the
-                                reference and is NOT taken.                                 */
+    uint32_t samples;        /* antialiasing_samples (camera.rs:24). 1 = one ray through the pixel
+                                centre. ANY other value, 0 included, takes render_pixel's second
+                                branch (camera.rs:99-113): the 4 fixed sub-samples at offsets
+                                (.25|.75, .25|.75) are averaged (Color::average_over), and if any of
+                                them is farther than 0.01 (Euclidean RGB, Color::distance_from
+                                color.rs:122-126) from that mean, `samples` MORE rays are traced,
+                                appended to the same list and the mean is taken again (resample,
+                                camera.rs:84-92). The trigger is deterministic and reproduced
+                                exactly; the reference draws the extra offsets from thread_rng
+                                (non-reproducible), so the resample itself is only taken with
+                                RTC_FLAG_AA_RESAMPLE, with offsets from a documented counter-based
+                                generator: for pixel (x, y) and extra sample k = 0..samples-1,
+                                  c = (uint64(y)*hsize + x) << 16
+                                  x_offset = (splitmix64(c | 2k)   >> 11) * 2^-53
+                                  y_offset = (splitmix64(c | 2k+1) >> 11) * 2^-53
+                                with splitmix64(z): z += 0x9E3779B97F4A7C15; z = (z ^ z>>30) *
+                                0xBF58476D1CE4E5B9; z = (z ^ z>>27) * 0x94D049BB133111EB; z ^ z>>31
+                                (uniform in [0,1) like rng.gen::<f64>()). samples == 0 resamples
+                                zero rays: the mean of the four is recomputed and is the result.
+                                Values above 255 are rejected (the reference's field is a u8).       */
     uint32_t _pad;
 } rtc_camera;
 
@@ -137,7 +163,9 @@ typedef struct rtc_stats {
     uint64_t rays_reflect;   /* reflected_color recursion           shape.rs:734-735   */
     uint64_t rays_refract;   /* refracted_color recursion           shape.rs:764-765   */
     uint64_t pixels;         /* pixels written by the last render                        */
-    uint64_t _reserved[3];
+    uint64_t pixels_resample;/* pixels whose 4 sub-samples trip the resample test
+                                (camera.rs:108-111); 0 when samples == 1                 */
+    uint64_t _reserved[2];
 } rtc_stats;
 
 /* Per-ray probe record filled by rtc_color_at: the fields of CachedVectors
@@ -160,7 +188,7 @@ typedef struct rtc_hit {
                                 shape.rs:692,752)                                       */
 } rtc_hit;
 
-typedef struct rtc_context rtc_context; /* one GPU + one stream; single-threaded use      */
+typedef struct rtc_context rtc_context; /* one GPU + one stream; single-threaded use (N GPUs: rtc_group) */
 typedef struct rtc_world   rtc_world;   /* flattened World resident in HBM                */
 
 /* ==== [host] reference-faithful setup arithmetic =================================== */
@@ -310,6 +338,75 @@ rtc_status  rtc_kernel_times_ms(rtc_context *ctx, float *out, uint32_t cap, uint
  * the pairs recorded so far: the next launch is the first of a new series. */
 rtc_status  rtc_context_set_timing(rtc_context *ctx, uint32_t every);
 rtc_status  rtc_last_kernel_ms(rtc_context *ctx, float *ms);
+
+/* Page-lock a canvas the CALLER allocated (a Rust `Vec<Color>`, canvas.rs:16-22: 24 bytes per pixel,
+ * the layout rtc_render writes) so that rtc_render / rtc_group_render_host fill it by DMA at link speed
+ * instead of through the runtime's bounce buffers. Unregister before the memory is freed. [device] */
+rtc_status  rtc_host_register(void *p, size_t bytes);
+rtc_status  rtc_host_unregister(void *p);
+
+/* ==== [device] row tiles across the GPUs of one node ================================ */
+/* Camera::render_async shards over pixels with no data dependency (camera.rs:144-160: every pixel is an
+ * independent work item of the rayon pool). A group is N GPUs that render one frame together: member r
+ * renders the 8-row bands r, r+N, r+2N, ... (rtc_render_bands), then ONE exchange step — an RCCL gather
+ * of the f64 tiles to member 0 over xGMI (ncclGather) — and one un-deal kernel on member 0's device puts
+ * the bands back in the reference's row-major Canvas (canvas.rs:43-51). The World (a few MB at most) is
+ * replicated. Two ways to form a group:
+ *   rtc_group_create       one process drives all `ndev` devices (ncclCommInitAll) — what a Rust host
+ *                          calling Camera::render_async would use;
+ *   rtc_group_create_rank  one process per GPU (torchrun / MPI style): every process creates its member
+ *                          with the same 128-byte id (ncclGetUniqueId on rank 0, shipped by the caller's
+ *                          launcher) — ncclCommInitRank.
+ * Each member owns two HIP streams (render, exchange) and two tile buffers: the gather of frame j
+ * overlaps the render of frame j+1. Calls enqueue and return; rtc_group_synchronize waits.
+ * A group is used from one thread at a time. */
+typedef struct rtc_group       rtc_group;
+typedef struct rtc_group_world rtc_group_world;
+#define RTC_GROUP_ID_BYTES 128u
+enum { /* rtc_group_create / rtc_group_create_rank `exchange` */
+    RTC_EXCHANGE_RCCL = 0, /* ncclGather of the f64 tiles (and of the 8-bit tiles when asked for) to member 0     */
+    RTC_EXCHANGE_P2P  = 1  /* in-process groups only: hipMemcpyPeerAsync of each tile into member 0's staging
+                              buffer (SDMA engines over xGMI, no CUs taken from the render); also the only
+                              exchange that accepts the same device more than once (rehearsal on a 1-GPU box) */
+};
+rtc_status  rtc_group_create(const int32_t *devices, uint32_t ndev, uint32_t exchange, rtc_group **out);
+rtc_status  rtc_group_unique_id(uint8_t id[RTC_GROUP_ID_BYTES]);
+rtc_status  rtc_group_create_rank(int32_t device, uint32_t nranks, uint32_t rank, const uint8_t id[RTC_GROUP_ID_BYTES],
+                                  rtc_group **out);
+void        rtc_group_destroy(rtc_group *g);
+uint32_t    rtc_group_size(const rtc_group *g);        /* N: members of the whole group                    */
+uint32_t    rtc_group_local_size(const rtc_group *g);  /* members this process drives (N, or 1)            */
+/* The i-th local member's context (stats, kernel timing, device info); owned by the group. */
+rtc_context *rtc_group_context(rtc_group *g, uint32_t i);
+rtc_status  rtc_group_synchronize(rtc_group *g);
+/* World::new + add_shape on every local member (replicated upload). */
+rtc_status  rtc_group_world_create(rtc_group *g, const rtc_shape *shapes, uint32_t n_shapes, const rtc_light *light,
+                                   rtc_group_world **out);
+void        rtc_group_world_destroy(rtc_group_world *w);
+/* Camera::render_async(&World) -> Canvas on all members, `nframes` (<= RTC_MAX_VIEWS_PER_LAUNCH) cameras of
+ * one size per call (one launch per member, as rtc_render_views). d_canvas: DEVICE memory on member 0's
+ * device, nframes consecutive canvases of vsize*hsize*3 doubles (frame f at f*vsize*hsize*3); required in
+ * the process that drives member 0, ignored elsewhere. d_rgb8 (may be NULL): the same frames quantised by
+ * Color::scale(c, 255), nframes*vsize*hsize*3 bytes — when given, the 8-bit tiles are gathered as well.
+ * `what` selects the exchange payload: */
+enum {
+    RTC_GATHER_F64  = 1u, /* the f64 Canvas (24 B/pixel): the path's own output                              */
+    RTC_GATHER_U8   = 2u, /* the 8-bit frame only (3 B/pixel, what every file writer of the reference consumes,
+                             canvas.rs:98-104); d_canvas is then not written                                  */
+    RTC_GATHER_NONE = 0u  /* render only: tiles stay on their GPUs (rtc_group_tile)                           */
+};
+rtc_status  rtc_group_render(rtc_group *g, const rtc_group_world *w, const rtc_camera *cams, uint32_t nframes,
+                             uint32_t mode, uint32_t flags, uint32_t what, void *d_canvas, void *d_rgb8);
+/* Camera::render_async(&World) -> Canvas in HOST memory: every local member renders its bands and DMAs them
+ * straight to their rows of `rgb` over its own PCIe link (no gather: N links fill the canvas side by side).
+ * `rgb` = vsize*hsize*3 doubles, ideally page-locked (rtc_host_alloc / rtc_host_register); with one process
+ * per GPU it is each process's mapping of one shared-memory canvas. Synchronous for the local members.
+ * `stats` (may be NULL) = the local members' ray counters for this frame. */
+rtc_status  rtc_group_render_host(rtc_group *g, const rtc_group_world *w, const rtc_camera *cam, uint32_t mode,
+                                  uint32_t flags, double *rgb, rtc_stats *stats);
+/* Ray counters of the local members, summed (per member: rtc_stats_read on rtc_group_context). */
+rtc_status  rtc_group_stats_read(rtc_group *g, rtc_stats *out);
+rtc_status  rtc_group_stats_reset(rtc_group *g);
 
 /* World::color_at(ray, remaining) (shape.rs:702-710) for `n` arbitrary host rays
  * (n x {origin xyz, direction xyz}); writes n x rgb and, if hits != NULL, the hit record

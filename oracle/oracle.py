@@ -80,6 +80,7 @@ def lib() -> C.CDLL:
             "orc_pattern_at": (None, [C.POINTER(RtcMaterial), Vec3, Vec3]),
             "orc_pattern_at_shape": (None, [C.POINTER(RtcMaterial), PS, Vec3, Vec3]),
             "orc_render": (None, [PS, U32, PL, PC, U32, U32, U32, PD, U32, C.c_int, C.POINTER(RtcStats)]),
+            "orc_render_flags": (None, [PS, U32, PL, PC, U32, U32, U32, U32, PD, U32, C.c_int, C.POINTER(RtcStats)]),
             "orc_format_ppm": (C.c_size_t, [PD, U32, U32, C.c_char_p, C.c_size_t]),
             "orc_color_scale": (I32, [D, I32]),
             "orc_canvas_to_rgba8": (None, [PD, U32, U32, C.c_float, C.POINTER(C.c_uint8)]),
@@ -165,11 +166,14 @@ def light(position=(-10.0, 10.0, -10.0), intensity=(1.0, 1.0, 1.0)) -> RtcLight:
     return l
 
 
-def world(shapes: list[RtcShape]):
+def world(shapes: list[RtcShape], u8_ids: bool = False):
+    """World::add_shape numbering (shape.rs:661-667). u8_ids=True reproduces the reference's own id type:
+    `last_world_id: u8` wraps in a release build, so shape 256 gets id 0, shape 257 id 1, ... and
+    compute_refractive (shape.rs:127) treats shapes that share an id as one container."""
     arr = (RtcShape * max(1, len(shapes)))()
     for i, s in enumerate(shapes):
         arr[i] = s
-        arr[i].world_id = i + 1
+        arr[i].world_id = ((i + 1) & 0xFF) if u8_ids else i + 1
     return arr
 
 
@@ -197,14 +201,18 @@ def color_at(shapes_arr, n, lgt, ray, remaining=5, streaming=False, want_hit=Fal
     return (out, hit) if want_hit else out
 
 
-def render(shapes_arr, n, lgt, cam, mode=1, y0=0, y1=None, nthreads=1, streaming=False, want_stats=False):
+def render(shapes_arr, n, lgt, cam, mode=1, y0=0, y1=None, nthreads=1, streaming=False, want_stats=False, flags=0):
     y1 = cam.vsize if y1 is None else y1
     out = np.zeros((y1 - y0, cam.hsize, 3), dtype=np.float64)
     st = RtcStats()
-    lib().orc_render(shapes_arr, n, C.byref(lgt), C.byref(cam), mode, y0, y1, out.ctypes.data_as(PD), nthreads, 1 if streaming else 0, C.byref(st))
+    lib().orc_render_flags(shapes_arr, n, C.byref(lgt), C.byref(cam), mode, flags, y0, y1, out.ctypes.data_as(PD), nthreads,
+                           1 if streaming else 0, C.byref(st))
     if want_stats:
-        return out, {"rays_primary": st.rays_primary, "rays_shadow": st.rays_shadow, "rays_reflect": st.rays_reflect,
-                     "rays_refract": st.rays_refract, "pixels": st.pixels}
+        d = {"rays_primary": st.rays_primary, "rays_shadow": st.rays_shadow, "rays_reflect": st.rays_reflect,
+             "rays_refract": st.rays_refract, "pixels": st.pixels}
+        if cam.samples != 1:
+            d["pixels_resample"] = st.pixels_resample
+        return out, d
     return out
 
 

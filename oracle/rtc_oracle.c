@@ -494,6 +494,7 @@ typedef struct {
     int32_t *idxs;
     counters_t *cnt;
     int streaming;
+    uint32_t *id_order; /* streaming form: shape indices in stable order of world_id */
 } trace_t;
 
 static void color_at_impl(trace_t *T, const double ray[6], uint32_t remaining, int kind,
@@ -606,32 +607,50 @@ static int streaming_first_hit(trace_t *T, const double ray[6], rtc_hit *out) {
     orc_normal_at(&T->shapes[h], p, normal);
     double n1 = 1.0, n2 = 1.0;
     if (T->shapes[h].material.transparency != 0.0) {
-        /* open set: objects with exactly their first entry before the hit entry in list order;
-         * containers.last = the open object whose opening entry is latest (max (t, index)). */
+        /* compute_refractive (shape.rs:115-141) without the sorted list. `containers` is keyed by
+         * world_id (shape.rs:127): every entry before the hit entry (list order = ascending (t, shape
+         * index), an object's first root before its second) toggles its id's membership. An id is
+         * present iff an odd number of its entries precede the hit entry; the element standing for it
+         * is the entry that pushed it last = the LAST of those entries; containers.last = the present
+         * id whose such entry is latest in list order. Shapes are visited grouped by id (T->id_order:
+         * stable sort by world_id), one class accumulator at a time. With unique ids this is the
+         * "open set" of SURVEY.md App. A.6; with shared ids (the reference's u8 ids wrap at 256
+         * shapes, shape.rs:287,661-667) it is still exactly the literal walk. n2: the hit entry
+         * toggles the hit shape's id once more. */
         int have_all = 0, have_oth = 0;
         double key_all = 0., key_oth = 0.;
         int32_t idx_all = -1, idx_oth = -1;
-        for (uint32_t s = 0; s < T->n; s++) {
-            double lt[2];
-            int c = orc_shape_intersect(&T->shapes[s], ray, lt);
-            if (c == 0) continue;
-            int open;
-            if ((int32_t)s == h) {
-                open = (root == 1); /* hit is this object's second entry: the first precedes it */
-            } else {
-                int p1 = lt[0] < best || (lt[0] == best && (int32_t)s < h);
-                int p2 = (c == 2) && (lt[1] < best || (lt[1] == best && (int32_t)s < h));
-                open = p1 && !p2;
+        const uint32_t hid = T->shapes[h].world_id;
+        uint32_t cnt_h = 0; /* entries of the hit's id class before the hit entry */
+        uint32_t k = 0;
+        while (k < T->n) {
+            const uint32_t id = T->shapes[T->id_order[k]].world_id;
+            uint32_t cnt = 0;
+            double last_t = 0.;
+            int32_t last_s = -1;
+            for (; k < T->n && T->shapes[T->id_order[k]].world_id == id; k++) {
+                const int32_t sidx = (int32_t)T->id_order[k];
+                double lt[2];
+                int c = orc_shape_intersect(&T->shapes[sidx], ray, lt);
+                for (int i = 0; i < c; i++) {
+                    int before;
+                    if (sidx == h) before = (i < root);
+                    else before = lt[i] < best || (lt[i] == best && sidx < h);
+                    if (!before) continue;
+                    cnt++;
+                    if (last_s < 0 || lt[i] > last_t || (lt[i] == last_t && sidx >= last_s)) { last_t = lt[i]; last_s = sidx; }
+                }
             }
-            if (!open) continue;
-            double key = lt[0];
-            if (!have_all || key > key_all || (key == key_all && (int32_t)s > idx_all)) { have_all = 1; key_all = key; idx_all = (int32_t)s; }
-            if ((int32_t)s != h)
-                if (!have_oth || key > key_oth || (key == key_oth && (int32_t)s > idx_oth)) { have_oth = 1; key_oth = key; idx_oth = (int32_t)s; }
+            if (id == hid) cnt_h = cnt;
+            if (cnt & 1u) {
+                if (!have_all || last_t > key_all || (last_t == key_all && last_s > idx_all)) { have_all = 1; key_all = last_t; idx_all = last_s; }
+                if (id != hid)
+                    if (!have_oth || last_t > key_oth || (last_t == key_oth && last_s > idx_oth)) { have_oth = 1; key_oth = last_t; idx_oth = last_s; }
+            }
         }
         n1 = have_all ? T->shapes[idx_all].material.refractive_index : 1.0;
-        if (root == 1) n2 = have_oth ? T->shapes[idx_oth].material.refractive_index : 1.0; /* h removed */
-        else n2 = T->shapes[h].material.refractive_index;                                /* h pushed  */
+        if (cnt_h & 1u) n2 = have_oth ? T->shapes[idx_oth].material.refractive_index : 1.0; /* the hit entry removes its id */
+        else n2 = T->shapes[h].material.refractive_index;                                   /* the hit entry pushes its id  */
     }
     cached_vectors_new(ray, best, h, p, eyev, normal, n1, n2, out);
     return 1;
@@ -675,9 +694,25 @@ static int trace_init(trace_t *T, const rtc_shape *shapes, uint32_t n, const rtc
     size_t cap = (size_t)LEVELS * 2 * (n ? n : 1);
     T->ts = (double *)malloc(cap * sizeof(double));
     T->idxs = (int32_t *)malloc(cap * sizeof(int32_t));
-    return (T->ts && T->idxs) ? 0 : 1;
+    T->id_order = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+    if (!(T->ts && T->idxs && T->id_order)) return 1;
+    /* stable counting-free sort by world_id (merge sort on indices; n is small next to the render) */
+    uint32_t *tmp = (uint32_t *)malloc((n ? n : 1) * sizeof(uint32_t));
+    if (!tmp) return 1;
+    for (uint32_t i = 0; i < n; i++) T->id_order[i] = i;
+    for (uint32_t w = 1; w < n; w *= 2) {
+        for (uint32_t lo = 0; lo < n; lo += 2 * w) {
+            uint32_t mid = lo + w < n ? lo + w : n, hi = lo + 2 * w < n ? lo + 2 * w : n, a = lo, b = mid, o = lo;
+            while (a < mid && b < hi) tmp[o++] = (shapes[T->id_order[b]].world_id < shapes[T->id_order[a]].world_id) ? T->id_order[b++] : T->id_order[a++];
+            while (a < mid) tmp[o++] = T->id_order[a++];
+            while (b < hi) tmp[o++] = T->id_order[b++];
+        }
+        memcpy(T->id_order, tmp, n * sizeof(uint32_t));
+    }
+    free(tmp);
+    return 0;
 }
-static void trace_free(trace_t *T) { free(T->ts); free(T->idxs); }
+static void trace_free(trace_t *T) { free(T->ts); free(T->idxs); free(T->id_order); }
 
 int orc_is_shadowed(const rtc_shape *shapes, uint32_t n, const rtc_light *light, const double p[3]) {
     trace_t T;
@@ -732,28 +767,56 @@ static void average_over(const double (*c)[3], int n, double out[3]) { /* color.
     out[0] = reds / l; out[1] = greens / l; out[2] = blues / l;
 }
 
-static void render_pixel(trace_t *T, const rtc_camera *cam, uint32_t x, uint32_t y, double rgb[3]) {
+/* Offsets of the resample rays. The reference draws them from rand::thread_rng (camera.rs:85-89),
+ * which nothing can reproduce; the product documents a counter-based generator instead (rtc.h,
+ * rtc_camera.samples) and this is its restatement: SplitMix64 of a per-(pixel, draw) counter. */
+static uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static double resample_offset(const rtc_camera *cam, uint32_t x, uint32_t y, uint32_t draw) {
+    const uint64_t ctr = (((uint64_t)y * cam->hsize + x) << 16) | draw;
+    return (double)(splitmix64(ctr) >> 11) * 0x1p-53;
+}
+
+/* returns 1 when the pixel's four sub-samples trip the resample test (camera.rs:108) */
+static int render_pixel(trace_t *T, const rtc_camera *cam, uint32_t x, uint32_t y, uint32_t flags, double rgb[3]) {
     /* camera.rs:94-114 */
     double ray[6];
     if (cam->samples == 1) {
         orc_camera_ray_for_pixel(cam, x, 0.5, y, 0.5, ray);
         color_at_impl(T, ray, RTC_MAX_REFLECTIONS, RAY_PRIMARY, 0, rgb, NULL);
-    } else {
-        static const double off[4][2] = {{0.25, 0.25}, {0.75, 0.25}, {0.25, 0.75}, {0.75, 0.75}};
-        double s[4][3];
-        for (int i = 0; i < 4; i++) {
-            orc_camera_ray_for_pixel(cam, x, off[i][0], y, off[i][1], ray);
-            color_at_impl(T, ray, RTC_MAX_REFLECTIONS, RAY_PRIMARY, 0, s[i], NULL);
-        }
-        average_over((const double (*)[3])s, 4, rgb);
-        /* the thread_rng resample branch (camera.rs:84-92,109-111) is non-deterministic in
-         * the reference and is not taken (rtc.h, rtc_camera.samples). */
+        return 0;
     }
+    static const double off[4][2] = {{0.25, 0.25}, {0.75, 0.25}, {0.25, 0.75}, {0.75, 0.75}};
+    const uint32_t extra = cam->samples & 0xffu; /* antialiasing_samples: u8 (camera.rs:24) */
+    double (*s)[3] = (double (*)[3])malloc(sizeof(double[3]) * (4 + extra));
+    for (int i = 0; i < 4; i++) {
+        orc_camera_ray_for_pixel(cam, x, off[i][0], y, off[i][1], ray);
+        color_at_impl(T, ray, RTC_MAX_REFLECTIONS, RAY_PRIMARY, 0, s[i], NULL);
+    }
+    average_over((const double (*)[3])s, 4, rgb);
+    int trip = 0;
+    for (int i = 0; i < 4; i++) { /* Color::distance_from color.rs:122-126: powi(2) = x*x */
+        const double dr = s[i][0] - rgb[0], dg = s[i][1] - rgb[1], db = s[i][2] - rgb[2];
+        if (sqrt(dr * dr + dg * dg + db * db) > 0.01) trip = 1;
+    }
+    if (trip && (flags & RTC_FLAG_AA_RESAMPLE)) { /* Camera::resample camera.rs:84-92 */
+        for (uint32_t k = 0; k < extra; k++) {
+            orc_camera_ray_for_pixel(cam, x, resample_offset(cam, x, y, 2 * k), y, resample_offset(cam, x, y, 2 * k + 1), ray);
+            color_at_impl(T, ray, RTC_MAX_REFLECTIONS, RAY_PRIMARY, 0, s[4 + k], NULL);
+        }
+        average_over((const double (*)[3])s, 4 + (int)extra, rgb);
+    }
+    free(s);
+    return trip;
 }
 
 typedef struct {
     const rtc_shape *shapes; uint32_t n; const rtc_light *light; const rtc_camera *cam;
-    uint32_t mode, y0, y1; double *rgb; int streaming; counters_t cnt; uint64_t pixels;
+    uint32_t mode, y0, y1, flags; double *rgb; int streaming; counters_t cnt; uint64_t pixels, resample;
     atomic_uint *next_row; /* shared work queue: workers take one canvas row at a time */
 } job_t;
 
@@ -762,6 +825,7 @@ static void *render_rows(void *arg) {
     trace_t T;
     memset(&j->cnt, 0, sizeof j->cnt);
     j->pixels = 0;
+    j->resample = 0;
     if (trace_init(&T, j->shapes, j->n, j->light, &j->cnt, j->streaming)) return NULL;
     uint32_t W = j->cam->hsize, H = j->cam->vsize;
     for (;;) {
@@ -772,7 +836,7 @@ static void *render_rows(void *arg) {
             /* Camera::render loops 0..vsize-1 and 0..hsize-1 EXCLUSIVE (camera.rs:120-121);
              * untouched pixels keep Canvas::new's BLACK (canvas.rs:37-41). */
             if (j->mode == RTC_MODE_RENDER && (x + 1 >= W || y + 1 >= H)) { px[0] = px[1] = px[2] = 0.; continue; }
-            render_pixel(&T, j->cam, x, y, px);
+            j->resample += (uint64_t)render_pixel(&T, j->cam, x, y, j->flags, px);
             j->pixels++;
         }
     }
@@ -783,6 +847,12 @@ static void *render_rows(void *arg) {
 void orc_render(const rtc_shape *shapes, uint32_t n, const rtc_light *light, const rtc_camera *cam,
                 uint32_t mode, uint32_t y0, uint32_t y1, double *rgb, uint32_t nthreads,
                 int streaming, rtc_stats *stats) {
+    orc_render_flags(shapes, n, light, cam, mode, 0u, y0, y1, rgb, nthreads, streaming, stats);
+}
+
+void orc_render_flags(const rtc_shape *shapes, uint32_t n, const rtc_light *light, const rtc_camera *cam,
+                      uint32_t mode, uint32_t flags, uint32_t y0, uint32_t y1, double *rgb, uint32_t nthreads,
+                      int streaming, rtc_stats *stats) {
     if (nthreads < 1) nthreads = 1;
     uint32_t rows = y1 - y0;
     if (nthreads > rows && rows > 0) nthreads = rows;
@@ -793,7 +863,7 @@ void orc_render(const rtc_shape *shapes, uint32_t n, const rtc_light *light, con
     for (uint32_t t = 0; t < nthreads; t++) {
         job_t *j = &jobs[t];
         j->shapes = shapes; j->n = n; j->light = light; j->cam = cam; j->mode = mode; j->y0 = y0; j->y1 = y1;
-        j->rgb = rgb; j->streaming = streaming; j->next_row = &next_row;
+        j->rgb = rgb; j->streaming = streaming; j->next_row = &next_row; j->flags = flags;
         if (nthreads == 1) render_rows(j);
         else pthread_create(&th[t], NULL, render_rows, j);
     }
@@ -804,6 +874,7 @@ void orc_render(const rtc_shape *shapes, uint32_t n, const rtc_light *light, con
         s.rays_primary += jobs[t].cnt.primary; s.rays_shadow += jobs[t].cnt.shadow;
         s.rays_reflect += jobs[t].cnt.reflect; s.rays_refract += jobs[t].cnt.refract;
         s.pixels += jobs[t].pixels;
+        s.pixels_resample += jobs[t].resample;
     }
     if (stats) *stats = s;
     free(jobs); free(th);

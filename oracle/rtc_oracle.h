@@ -110,6 +110,12 @@ void   orc_pattern_at_shape(const rtc_material *m, const rtc_shape *shape,
 void   orc_render(const rtc_shape *shapes, uint32_t n, const rtc_light *light,
                   const rtc_camera *cam, uint32_t mode, uint32_t y0, uint32_t y1,
                   double *rgb, uint32_t nthreads, int streaming, rtc_stats *stats);
+/* The same with render flags: RTC_FLAG_AA_RESAMPLE takes render_pixel's resample branch
+ * (camera.rs:84-92,108-111) with the counter-based offsets rtc.h documents (the reference's come from
+ * thread_rng); without it the tripped pixels keep the 4-sample mean. stats->pixels_resample counts them. */
+void   orc_render_flags(const rtc_shape *shapes, uint32_t n, const rtc_light *light,
+                        const rtc_camera *cam, uint32_t mode, uint32_t flags, uint32_t y0, uint32_t y1,
+                        double *rgb, uint32_t nthreads, int streaming, rtc_stats *stats);
 /* Canvas::write_to_file_simple (canvas.rs:86-109) into memory; returns bytes needed. */
 void orc_canvas_to_rgba8(const double *rgb, uint32_t width, uint32_t height, float gamma, uint8_t *out);
 size_t orc_format_ppm(const double *rgb, uint32_t width, uint32_t height, char *buf, size_t cap);

@@ -18,7 +18,8 @@ from pathlib import Path
 import numpy as np
 
 from .abi import (RtcCamera, RtcHit, RtcLight, RtcMaterial, RtcShape, RtcStats, Mat16, Vec3,
-                  SPHERE, PLANE, CUBE, MODE_RENDER, MODE_RENDER_ASYNC, PATTERNS, STATUS_NAMES, declare)
+                  SPHERE, PLANE, CUBE, MODE_RENDER, MODE_RENDER_ASYNC, FLAG_NONE, FLAG_NO_CULL, FLAG_AA_RESAMPLE,
+                  EXCHANGE_RCCL, EXCHANGE_P2P, GATHER_NONE, GATHER_F64, GATHER_U8, GROUP_ID_BYTES, PATTERNS, STATUS_NAMES, declare)
 
 PKG = Path(__file__).resolve().parent
 LIB_PATH = PKG / "librtc.so"
@@ -283,15 +284,28 @@ def write_ppm(path, rgb: np.ndarray) -> None:
 # ---------------------------------------------------------------------------------------
 # device side
 # ---------------------------------------------------------------------------------------
+def _stats_dict(s: RtcStats, with_resample: bool = False) -> dict:
+    d = {"rays_primary": s.rays_primary, "rays_shadow": s.rays_shadow, "rays_reflect": s.rays_reflect,
+         "rays_refract": s.rays_refract, "pixels": s.pixels}
+    if with_resample or s.pixels_resample:
+        d["pixels_resample"] = s.pixels_resample
+    return d
+
+
 class Context:
     """One GPU + one stream (rtc_context). `stream` is a raw hipStream_t value (int) or None."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
+    def __init__(self, device: int = 0, stream: int | None = None, _borrowed=None):
+        self._worlds = []  # weak references to the worlds uploaded through this context
+        self._owned = _borrowed is None
+        if _borrowed is not None:   # a group member's context: owned by the group
+            self._h = C.c_void_p(_borrowed)
+            self.device = device
+            return
         self._h = C.c_void_p()
         _check(lib().rtc_context_create(device, C.c_void_p(stream or None), C.byref(self._h)), "rtc_context_create",
                "no usable MI355X (gfx950); this library has no CPU fallback")
         self.device = device
-        self._worlds = []  # weak references to the worlds uploaded through this context
 
     def close(self):
         if self._h:
@@ -300,7 +314,8 @@ class Context:
                 if w is not None:
                     w.close()
             self._worlds = []
-            lib().rtc_context_destroy(self._h)
+            if self._owned:
+                lib().rtc_context_destroy(self._h)
             self._h = C.c_void_p()
 
     def __del__(self):
@@ -324,8 +339,7 @@ class Context:
     def stats(self) -> dict:
         s = RtcStats()
         _check(lib().rtc_stats_read(self._h, C.byref(s)), "rtc_stats_read")
-        return {"rays_primary": s.rays_primary, "rays_shadow": s.rays_shadow, "rays_reflect": s.rays_reflect,
-                "rays_refract": s.rays_refract, "pixels": s.pixels}
+        return _stats_dict(s)
 
     def reset_stats(self):
         _check(lib().rtc_stats_reset(self._h), "rtc_stats_reset")
@@ -414,8 +428,7 @@ class DeviceWorld:
         _check(lib().rtc_render(self.ctx._h, self._h, C.byref(cam), mode, flags, out.ctypes.data_as(C.POINTER(C.c_double)),
                                 C.byref(st) if with_stats else None), "rtc_render")
         if with_stats:
-            return out, {"rays_primary": st.rays_primary, "rays_shadow": st.rays_shadow, "rays_reflect": st.rays_reflect,
-                         "rays_refract": st.rays_refract, "pixels": st.pixels}
+            return out, _stats_dict(st, cam.samples != 1)
         return out
 
     def render_rows(self, cam: RtcCamera, y0: int, y1: int, d_ptr: int, mode: int = MODE_RENDER_ASYNC, flags: int = 0,
@@ -455,6 +468,115 @@ class DeviceWorld:
         return (rgb, hits) if want_hits else rgb
 
 
+def host_register(arr: np.ndarray) -> None:
+    """rtc_host_register: page-lock a canvas the caller allocated (a Vec<Color> on the Rust side)."""
+    _check(lib().rtc_host_register(C.c_void_p(arr.ctypes.data), arr.nbytes), "rtc_host_register")
+
+
+def host_unregister(arr: np.ndarray) -> None:
+    _check(lib().rtc_host_unregister(C.c_void_p(arr.ctypes.data)), "rtc_host_unregister")
+
+
+def group_unique_id() -> bytes:
+    """ncclGetUniqueId through the C-ABI (rank 0 calls it and ships the 128 bytes to the other ranks)."""
+    buf = (C.c_uint8 * GROUP_ID_BYTES)()
+    _check(lib().rtc_group_unique_id(buf), "rtc_group_unique_id", "RCCL not loadable")
+    return bytes(buf)
+
+
+class Group:
+    """N GPUs rendering one frame together (rtc_group): 8-row bands dealt round-robin, RCCL gather of the
+    f64 tiles to member 0, un-deal on member 0's device. Group(devices=[...]) drives all devices from this
+    process; Group(device=d, nranks=N, rank=r, uid=...) is one member of a one-process-per-GPU group."""
+
+    def __init__(self, devices=None, exchange: int = EXCHANGE_RCCL, device: int | None = None, nranks: int | None = None,
+                 rank: int | None = None, uid: bytes | None = None):
+        self._h = C.c_void_p()
+        if devices is not None:
+            arr = (C.c_int32 * len(devices))(*devices)
+            _check(lib().rtc_group_create(arr, len(devices), exchange, C.byref(self._h)), "rtc_group_create")
+        else:
+            idb = (C.c_uint8 * GROUP_ID_BYTES)(*uid)
+            _check(lib().rtc_group_create_rank(device, nranks, rank, idb, C.byref(self._h)), "rtc_group_create_rank")
+        self.size = lib().rtc_group_size(self._h)
+        self.local_size = lib().rtc_group_local_size(self._h)
+        self.contexts = [Context(_borrowed=lib().rtc_group_context(self._h, i)) for i in range(self.local_size)]
+        self._worlds = []
+
+    def close(self):
+        if self._h:
+            for ref in self._worlds:
+                w = ref()
+                if w is not None:
+                    w.close()
+            self._worlds = []
+            for c in self.contexts:
+                c.close()
+            lib().rtc_group_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(lib().rtc_group_synchronize(self._h), "rtc_group_synchronize")
+
+    def upload(self, world: World) -> "GroupWorld":
+        return GroupWorld(self, world)
+
+    def stats(self) -> dict:
+        s = RtcStats()
+        _check(lib().rtc_group_stats_read(self._h, C.byref(s)), "rtc_group_stats_read")
+        return _stats_dict(s)
+
+    def reset_stats(self):
+        _check(lib().rtc_group_stats_reset(self._h), "rtc_group_stats_reset")
+
+
+class GroupWorld:
+    """World replicated on every local member of a Group (rtc_group_world)."""
+
+    def __init__(self, group: Group, world: World):
+        self.group = group
+        self._h = C.c_void_p()
+        _check(lib().rtc_group_world_create(group._h, world.array(), len(world.shapes), C.byref(world.light), C.byref(self._h)),
+               "rtc_group_world_create")
+        group._worlds.append(weakref.ref(self))
+
+    def close(self):
+        if self._h:
+            lib().rtc_group_world_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def render(self, cams, what: int = GATHER_F64, d_canvas: int | None = None, d_rgb8: int | None = None,
+               mode: int = MODE_RENDER_ASYNC, flags: int = 0) -> None:
+        """Enqueue one batch (<= 8 cameras of one size): every member renders its bands, the tiles are gathered to
+        member 0 and un-dealt into `d_canvas` (DEVICE address on member 0's device; frames back to back)."""
+        arr = cams if isinstance(cams, C.Array) else (RtcCamera * len(cams))(*cams)
+        st = lib().rtc_group_render(self.group._h, self._h, arr, len(arr), mode, flags, what, d_canvas, d_rgb8)
+        if st != 0:
+            raise RtcError(st, "rtc_group_render")
+
+    def render_host(self, cam: RtcCamera, out: np.ndarray, mode: int = MODE_RENDER_ASYNC, flags: int = 0, with_stats: bool = False):
+        """Camera::render_async -> host Canvas: every local member DMAs its bands straight into `out`."""
+        if out.shape != (cam.vsize, cam.hsize, 3) or out.dtype != np.float64 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous (vsize, hsize, 3) float64 array")
+        st = RtcStats()
+        _check(lib().rtc_group_render_host(self.group._h, self._h, C.byref(cam), mode, flags, out.ctypes.data_as(C.POINTER(C.c_double)),
+                                           C.byref(st) if with_stats else None), "rtc_group_render_host")
+        return (out, _stats_dict(st, cam.samples != 1)) if with_stats else out
+
+
 __all__ = ["lib", "RtcError", "Matrix", "material", "sphere", "plane", "cube", "light", "World", "camera", "ray_for_pixel",
-           "load_yaml", "format_ppm", "write_ppm", "color_scale255", "Context", "DeviceWorld", "MODE_RENDER", "MODE_RENDER_ASYNC",
+           "load_yaml", "format_ppm", "write_ppm", "color_scale255", "Context", "DeviceWorld", "MODE_RENDER", "MODE_RENDER_ASYNC", "FLAG_NONE", "FLAG_NO_CULL", "FLAG_AA_RESAMPLE", "Group", "GroupWorld", "group_unique_id",
+           "host_register", "host_unregister", "EXCHANGE_RCCL", "EXCHANGE_P2P", "GATHER_NONE", "GATHER_F64", "GATHER_U8",
            "SPHERE", "PLANE", "CUBE", "RtcCamera", "RtcHit", "RtcLight", "RtcMaterial", "RtcShape", "RtcStats"]

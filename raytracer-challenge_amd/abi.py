@@ -8,6 +8,10 @@ Vec3 = C.c_double * 3
 
 SPHERE, PLANE, CUBE = 0, 1, 2
 MODE_RENDER, MODE_RENDER_ASYNC = 0, 1
+FLAG_NONE, FLAG_NO_CULL, FLAG_AA_RESAMPLE = 0, 1, 2
+EXCHANGE_RCCL, EXCHANGE_P2P = 0, 1
+GATHER_NONE, GATHER_F64, GATHER_U8 = 0, 1, 2
+GROUP_ID_BYTES = 128
 PATTERNS = {"none": 0, "test": 1, "stripe": 2, "stripes": 2, "gradient": 3, "ring": 4, "checker": 5, "checkers": 5, "grid": 6}
 STATUS_NAMES = {0: "RTC_OK", 1: "RTC_ERR_SINGULAR", 2: "RTC_ERR_NO_COLOR", 3: "RTC_ERR_DEVICE", 4: "RTC_ERR_ARG",
                 5: "RTC_ERR_PARSE", 6: "RTC_ERR_IO", 7: "RTC_ERR_NOMEM", 8: "RTC_ERR_UNSUPPORTED"}
@@ -36,7 +40,7 @@ class RtcCamera(C.Structure):
 
 class RtcStats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
-                ("rays_refract", C.c_uint64), ("pixels", C.c_uint64), ("_reserved", C.c_uint64 * 3)]
+                ("rays_refract", C.c_uint64), ("pixels", C.c_uint64), ("pixels_resample", C.c_uint64), ("_reserved", C.c_uint64 * 2)]
 
 
 class RtcHit(C.Structure):
@@ -100,6 +104,22 @@ PROTOTYPES = {
     "rtc_kernel_times_ms": (C.c_int32, [VP, C.POINTER(C.c_float), U32, C.POINTER(U32)]),
     "rtc_context_set_timing": (C.c_int32, [VP, U32]),
     "rtc_last_kernel_ms": (C.c_int32, [VP, C.POINTER(C.c_float)]),
+    "rtc_host_register": (C.c_int32, [VP, C.c_size_t]),
+    "rtc_host_unregister": (C.c_int32, [VP]),
+    "rtc_group_create": (C.c_int32, [C.POINTER(C.c_int32), U32, U32, C.POINTER(VP)]),
+    "rtc_group_unique_id": (C.c_int32, [C.POINTER(C.c_uint8)]),
+    "rtc_group_create_rank": (C.c_int32, [C.c_int32, U32, U32, C.POINTER(C.c_uint8), C.POINTER(VP)]),
+    "rtc_group_destroy": (None, [VP]),
+    "rtc_group_size": (U32, [VP]),
+    "rtc_group_local_size": (U32, [VP]),
+    "rtc_group_context": (VP, [VP, U32]),
+    "rtc_group_synchronize": (C.c_int32, [VP]),
+    "rtc_group_world_create": (C.c_int32, [VP, C.POINTER(RtcShape), U32, C.POINTER(RtcLight), C.POINTER(VP)]),
+    "rtc_group_world_destroy": (None, [VP]),
+    "rtc_group_render": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, U32, U32, VP, VP]),
+    "rtc_group_render_host": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, PD, C.POINTER(RtcStats)]),
+    "rtc_group_stats_read": (C.c_int32, [VP, C.POINTER(RtcStats)]),
+    "rtc_group_stats_reset": (C.c_int32, [VP]),
     "rtc_color_at": (C.c_int32, [VP, VP, PD, U32, U32, U32, PD, C.POINTER(RtcHit)]),
     "rtc_device_arith": (C.c_int32, [VP, U32, PD, PD, U32, PD]),
 }

@@ -17,7 +17,7 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "librtc.so"
 
-SOURCES = ["host_math.cpp", "host_ppm.cpp", "host_yaml.cpp", "rtc_api.cpp", "rtc_kernels.hip"]
+SOURCES = ["host_math.cpp", "host_ppm.cpp", "host_yaml.cpp", "rtc_api.cpp", "rtc_group.cpp", "rtc_kernels.hip"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
 COMMON += os.environ.get("RTC_CXXFLAGS", "").split()  # experiments, e.g. -DRTC_WAVES_PER_SIMD=4
 # Kernel file only: MachineLICM hoists the VGPR materialisation of every f64 literal (pow's ~25
@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     cc = hipcc()
     objdir = ROOT / "build" / "rtc"
     objdir.mkdir(parents=True, exist_ok=True)
-    headers = [ROOT / "include" / "rtc.h", CSRC / "rtc_device.h"]
+    headers = [ROOT / "include" / "rtc.h", CSRC / "rtc_device.h", CSRC / "rtc_internal.h"]
     objs = []
     for name in SOURCES:
         src = CSRC / name
@@ -59,7 +59,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
                 print(" ".join(cmd), file=sys.stderr)
             subprocess.run(cmd, check=True)
     if force or _stale(LIB, objs):
-        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs), "-ldl"]
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.run(cmd, check=True)

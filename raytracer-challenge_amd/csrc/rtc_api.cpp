@@ -14,6 +14,7 @@
 
 #include "rtc.h"
 #include "rtc_device.h"
+#include "rtc_internal.h"
 
 extern "C" hipError_t rtc_launch_trace(const RenderParams *P, int src, int refl, int refr, uint32_t nblocks,
                                        size_t lds_bytes, hipStream_t stream, hipEvent_t e0, hipEvent_t e1);
@@ -21,46 +22,6 @@ extern "C" hipError_t rtc_launch_prep(const DevIsect *isect, DevPrim *prim, uint
                                       hipStream_t stream);
 extern "C" hipError_t rtc_launch_arith(uint32_t op, const double *a, const double *b, uint32_t n, double *out,
                                        hipStream_t stream);
-
-enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2, SRC_CULL = 3, SRC_CULL2 = 4 };
-
-struct rtc_context {
-    int device = -1;
-    hipStream_t stream = nullptr;
-    unsigned long long *d_counters = nullptr;
-    // ring of (begin, end) event pairs, one per k_trace launch of rtc_render_rows / rtc_render_bands
-    // (all created with the context: creating them lazily put two hipEventCreate calls on the launch
-    // path of the first 1024 frames)
-    static constexpr uint32_t EV_RING = 1024;
-    hipEvent_t ev[EV_RING][2] = {};
-    uint64_t launches = 0; // render launches so far
-    uint64_t timed = 0;    // ... of which carried an event pair (ring position)
-    uint32_t time_every = 1; // rtc_context_set_timing
-    // device canvas of rtc_render (host-canvas entry point): grow-only, reused between frames
-    double *d_canvas = nullptr;
-    size_t canvas_bytes = 0;
-    int force_src = -1;   // RTC_SRC env override (experiments)
-    uint32_t tile_cap = 512;
-};
-
-struct rtc_world {
-    rtc_context *ctx = nullptr; // identity check only; never dereferenced at destroy time
-    int device = -1;
-    uint32_t n = 0;
-    DevIsect *d_isect = nullptr;
-    uint32_t *d_kind = nullptr;
-    DevShade *d_shade = nullptr;
-    DevPrim *d_prim = nullptr;
-    DevBound *d_bound = nullptr;
-    DevIsect *d_isect_s = nullptr; // Morton-sorted copies for the two-level cull
-    uint32_t *d_kind_s = nullptr;
-    DevBound *d_bound_s = nullptr;
-    uint32_t *d_orig_s = nullptr;
-    DevBound *d_gbound = nullptr;
-    uint32_t ngroups = 0;
-    rtc_light light{};
-    bool any_refl = false, any_refr = false;
-};
 
 namespace {
 
@@ -222,7 +183,9 @@ void fill_camera(RenderParams &P, const rtc_camera *cam, uint32_t view = 0) {
     if (view == 0) {
         P.W = cam->hsize;
         P.H = cam->vsize;
-        P.samples = cam->samples ? cam->samples : 1;
+        // antialiasing_samples == 1 is the one-ray branch; every other value (0 included) the sub-sample
+        // branch (camera.rs:96-99)
+        P.samples = cam->samples == 1u ? 1u : 4u;
     }
     DevCamera &c = P.views[view];
     c.half_width = cam->half_width;
@@ -242,6 +205,7 @@ void fill_world(RenderParams &P, const rtc_world *w) {
     P.bound_s = w->d_bound_s;
     P.orig_s = w->d_orig_s;
     P.gbound = w->d_gbound;
+    P.idtab = w->d_idtab;
     P.ngroups = w->ngroups;
     P.n = w->n;
     for (int i = 0; i < 3; ++i) {
@@ -273,12 +237,6 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
         rtc_context_destroy(ctx);
         return RTC_ERR_DEVICE;
     }
-    for (auto &pair : ctx->ev)
-        for (hipEvent_t &e : pair)
-            if (hipEventCreate(&e) != hipSuccess) {
-                rtc_context_destroy(ctx);
-                return RTC_ERR_DEVICE;
-            }
     if (const char *e = std::getenv("RTC_SRC")) {
         const int v = std::atoi(e);
         if (v >= 0 && v <= 4) ctx->force_src = v;
@@ -340,6 +298,15 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
     std::memset(isect.data(), 0, sizeof(DevIsect) * na);
     std::memset(shade.data(), 0, sizeof(DevShade) * na);
     bool any_refl = false, any_refr = false;
+    // World::add_shape numbers the shapes last_world_id + 1 (shape.rs:661-667). A caller that leaves every id
+    // 0 (rtc_shape_init does) gets exactly that numbering; ids that were given are honoured as they are —
+    // equal ids are ONE container to compute_refractive (shape.rs:127), which is also what the reference's
+    // own u8 ids do beyond 255 shapes.
+    bool all_zero = true;
+    for (uint32_t i = 0; i < n; ++i) all_zero = all_zero && shapes[i].world_id == 0u;
+    std::vector<DevIdEntry> idtab(na, DevIdEntry{0u, 0u});
+    for (uint32_t i = 0; i < n; ++i) idtab[i] = DevIdEntry{i, all_zero ? i + 1u : shapes[i].world_id};
+    std::stable_sort(idtab.begin(), idtab.begin() + n, [](const DevIdEntry &a, const DevIdEntry &b) { return a.id < b.id; });
     for (uint32_t i = 0; i < n; ++i) {
         const rtc_shape &s = shapes[i];
         const rtc_material &m = s.material;
@@ -380,7 +347,7 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
         }
         d.kind = s.kind;
         d.pattern_kind = m.pattern_kind;
-        d.world_id = s.world_id;
+        d.world_id = all_zero ? i + 1u : s.world_id;
         if (m.reflective > 0.) any_refl = true;     // reflected_color shape.rs:730
         if (m.transparency != 0.0) any_refr = true; // refracted_color shape.rs:752
         bound[i] = bound_of(s);
@@ -460,7 +427,8 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
               hipMalloc(&w->d_kind_s, sizeof(uint32_t) * na) == hipSuccess &&
               hipMalloc(&w->d_bound_s, sizeof(DevBound) * na) == hipSuccess &&
               hipMalloc(&w->d_orig_s, sizeof(uint32_t) * na) == hipSuccess &&
-              hipMalloc(&w->d_gbound, sizeof(DevBound) * gbound.size()) == hipSuccess;
+              hipMalloc(&w->d_gbound, sizeof(DevBound) * gbound.size()) == hipSuccess &&
+              hipMalloc(&w->d_idtab, sizeof(DevIdEntry) * na) == hipSuccess;
     ok = ok && hipMemcpy(w->d_isect, isect.data(), sizeof(DevIsect) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_kind, kind.data(), sizeof(uint32_t) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_shade, shade.data(), sizeof(DevShade) * na, hipMemcpyHostToDevice) == hipSuccess &&
@@ -470,6 +438,7 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
          hipMemcpy(w->d_bound_s, bound_s.data(), sizeof(DevBound) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_orig_s, orig_s.data(), sizeof(uint32_t) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_gbound, gbound.data(), sizeof(DevBound) * gbound.size(), hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(w->d_idtab, idtab.data(), sizeof(DevIdEntry) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(w->d_prim, 0, sizeof(DevPrim) * na) == hipSuccess;
     if (!ok) {
         rtc_world_destroy(w);
@@ -495,6 +464,7 @@ void rtc_world_destroy(rtc_world *w) {
     if (w->d_bound_s) (void)hipFree(w->d_bound_s);
     if (w->d_orig_s) (void)hipFree(w->d_orig_s);
     if (w->d_gbound) (void)hipFree(w->d_gbound);
+    if (w->d_idtab) (void)hipFree(w->d_idtab);
     delete w;
 }
 
@@ -525,12 +495,27 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     size_t lds_bytes;
     choose_source(ctx, w->n, flags, &src, &P.tile_cap, &lds_bytes);
     P.flags = flags;
+    if (P.samples != 1u) { // the 4 sub-samples of every pixel wait in LDS for the resample test (camera.rs:108)
+        P.aa_lds_off = (uint32_t)lds_bytes;
+        lds_bytes += (size_t)RTC_BLOCK_OF(w->any_refl || w->any_refr) * 12u * sizeof(double);
+        // Camera::resample traces `antialiasing_samples` more rays (camera.rs:87); u8 in the reference
+        P.resample_n = (flags & RTC_FLAG_AA_RESAMPLE) ? (cam->samples & 0xffu) : 0u;
+    }
     // per-render prologue table of the brute-force variants (the culled kernels do not use it)
     if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.views[0].vinv, ctx->stream));
     // start/stop events cost ~9 us of host time and ~5 us of GPU time per launch (measured): callers
     // that are launch-bound sample every n-th launch instead (rtc_context_set_timing)
     const bool timed = ctx->time_every != 0 && ctx->launches % ctx->time_every == 0;
-    hipEvent_t *pair = ctx->ev[ctx->timed % rtc_context::EV_RING];
+    const uint32_t slot = (uint32_t)(ctx->timed % rtc_context::EV_RING);
+    if (timed && slot >= ctx->ev_created) { // next chunk of the ring
+        const uint32_t upto = std::min<uint32_t>(rtc_context::EV_RING, ctx->ev_created + rtc_context::EV_CHUNK);
+        for (uint32_t k = ctx->ev_created; k < upto; ++k) {
+            HIP_TRY(hipEventCreate(&ctx->ev[k][0]));
+            HIP_TRY(hipEventCreate(&ctx->ev[k][1]));
+            ctx->ev_created = k + 1;
+        }
+    }
+    hipEvent_t *pair = ctx->ev[slot];
     HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y * nviews, lds_bytes, ctx->stream,
                              timed ? pair[0] : nullptr, timed ? pair[1] : nullptr));
     ++ctx->launches;
@@ -542,6 +527,7 @@ rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camer
                            uint32_t y1, void *d_rgb, void *d_rgb8, uint32_t flags) {
     if (!ctx || !w || !cam || !d_rgb || w->ctx != ctx) return RTC_ERR_ARG;
     if (mode > RTC_MODE_RENDER_ASYNC || cam->hsize == 0 || cam->vsize == 0 || y0 > y1 || y1 > cam->vsize) return RTC_ERR_ARG;
+    if (cam->samples > 255u) return RTC_ERR_ARG; // antialiasing_samples is a u8 (camera.rs:24)
     if (y0 == y1) return RTC_OK;
     return render_launch(ctx, w, cam, mode, y0, y1, 1u, (y1 - y0 + 7u) / 8u, d_rgb, d_rgb8, flags);
 }
@@ -550,6 +536,7 @@ rtc_status rtc_render_bands(rtc_context *ctx, const rtc_world *w, const rtc_came
                             uint32_t first_band, uint32_t band_stride, void *d_rgb, void *d_rgb8, uint32_t flags) {
     if (!ctx || !w || !cam || !d_rgb || w->ctx != ctx) return RTC_ERR_ARG;
     if (mode > RTC_MODE_RENDER_ASYNC || cam->hsize == 0 || cam->vsize == 0 || band_stride == 0) return RTC_ERR_ARG;
+    if (cam->samples > 255u) return RTC_ERR_ARG;
     const uint32_t nbands = (cam->vsize + RTC_BAND_ROWS - 1u) / RTC_BAND_ROWS;
     if (first_band >= nbands) return RTC_OK; // this caller owns no band of so small a canvas
     const uint32_t mine = (nbands - first_band + band_stride - 1u) / band_stride;
@@ -571,6 +558,7 @@ rtc_status rtc_stats_read(rtc_context *ctx, rtc_stats *out) {
     out->rays_reflect = h[CNT_REFLECT];
     out->rays_refract = h[CNT_REFRACT];
     out->pixels = h[CNT_PIXELS];
+    out->pixels_resample = h[CNT_RESAMPLE];
     return RTC_OK;
 }
 
@@ -636,9 +624,9 @@ rtc_status rtc_render_views(rtc_context *ctx, const rtc_world *w, const rtc_came
     if (nviews == 0 || nviews > RTC_MAX_VIEWS_PER_LAUNCH || band_stride == 0 || mode > RTC_MODE_RENDER_ASYNC) return RTC_ERR_ARG;
     if (cams[0].hsize == 0 || cams[0].vsize == 0) return RTC_ERR_ARG;
     for (uint32_t v = 1; v < nviews; ++v)
-        if (cams[v].hsize != cams[0].hsize || cams[v].vsize != cams[0].vsize ||
-            (cams[v].samples ? cams[v].samples : 1) != (cams[0].samples ? cams[0].samples : 1))
+        if (cams[v].hsize != cams[0].hsize || cams[v].vsize != cams[0].vsize || cams[v].samples != cams[0].samples)
             return RTC_ERR_ARG; // one grid, one sampling pattern per launch
+    if (cams[0].samples > 255u) return RTC_ERR_ARG;
     const uint32_t nbands = (cams[0].vsize + RTC_BAND_ROWS - 1u) / RTC_BAND_ROWS;
     if (first_band >= nbands) return RTC_OK;
     const uint32_t mine = (nbands - first_band + band_stride - 1u) / band_stride;
@@ -664,7 +652,7 @@ rtc_status rtc_render_views(rtc_context *ctx, const rtc_world *w, const rtc_came
 
 rtc_status rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode, uint32_t flags,
                       double *rgb, rtc_stats *stats) {
-    if (!ctx || !w || !cam || !rgb) return RTC_ERR_ARG;
+    if (!ctx || !w || !cam || !rgb || w->ctx != ctx) return RTC_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     const size_t bytes = sizeof(double) * 3 * (size_t)cam->hsize * cam->vsize;
     if (bytes == 0) return RTC_ERR_ARG;
@@ -700,6 +688,19 @@ rtc_status rtc_host_alloc(size_t bytes, void **out) {
 
 void rtc_host_free(void *p) {
     if (p) (void)hipHostFree(p);
+}
+
+rtc_status rtc_host_register(void *p, size_t bytes) {
+    if (!p || bytes == 0) return RTC_ERR_ARG;
+    const hipError_t e = hipHostRegister(p, bytes, hipHostRegisterDefault);
+    if (e == hipErrorOutOfMemory) return RTC_ERR_NOMEM;
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return RTC_OK; }
+    return e == hipSuccess ? RTC_OK : RTC_ERR_DEVICE;
+}
+
+rtc_status rtc_host_unregister(void *p) {
+    if (!p) return RTC_ERR_ARG;
+    return hipHostUnregister(p) == hipSuccess ? RTC_OK : RTC_ERR_DEVICE;
 }
 
 rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays, uint32_t n, uint32_t remaining,

@@ -40,6 +40,12 @@ struct DevPrim {
     double c;          // (o.o) - 1.   (shape.rs:366)
 };
 
+// One shape of the id-ordered walk of the n1/n2 pass: World.shapes index + its world_id
+// (shape.rs:127 compares ids; shapes sharing an id are one container).
+struct DevIdEntry {
+    uint32_t index, id;
+};
+
 struct DevBound {
     double cx, cy, cz, r; // world-space bounding sphere; r = +inf: unbounded (planes) or not
                           // computable -> never culled
@@ -59,7 +65,7 @@ struct DevBound {
 // is r * (1 + k * D * (cn + D)) with k = 0.75e-14 * ||A||_F^2 (any upper bound of D may be used).
 // For ordinary scenes the factor is 1 + 1e-9.
 
-enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PIXELS = 4, CNT_STAMP0 = 8, CNT_DIAG0 = 16, CNT_N = 24 };
+enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PIXELS = 4, CNT_RESAMPLE = 5, CNT_STAMP0 = 8, CNT_DIAG0 = 16, CNT_N = 24 };
 // Ray counters are kept in CNT_SLOTS replicas (one 64-byte line each); a wave adds to the replica
 // picked by its workgroup id, so no single word sees more than 1/CNT_SLOTS of the atomics. The host
 // sums the replicas (rtc_stats_read).
@@ -100,12 +106,17 @@ struct RenderParams {
     const DevBound *bound_s;   // [n]
     const uint32_t *orig_s;    // [n] sorted position -> insertion index (World.shapes order)
     const DevBound *gbound;    // [ngroups] sphere around each group of 64 sorted objects
+    const DevIdEntry *idtab;   // [n] shapes in stable order of world_id (compute_refractive's container key)
     uint32_t ngroups;
     uint32_t n;
     uint32_t tile_cap; // objects per LDS tile (LDS variants)
     double light_pos[3], light_int[3];
     // camera (camera.rs:17-27)
-    uint32_t W, H, y0, y1, mode, samples;
+    uint32_t W, H, y0, y1, mode;
+    uint32_t samples;     // 1: one ray per pixel (camera.rs:96-98); anything else: the 4 fixed sub-samples
+                          // + the resample test (camera.rs:99-113) — 0 is normalised to 4 by the host
+    uint32_t resample_n;  // RTC_FLAG_AA_RESAMPLE: rays added by Camera::resample (antialiasing_samples), else 0
+    uint32_t aa_lds_off;  // samples != 1: byte offset of the sub-sample store inside the dynamic LDS block
     // A launch renders `nviews` cameras of the same size onto the same World (rtc_render_views: the
     // frames of a camera move, a stereo pair): workgroups [v*tiles, (v+1)*tiles) belong to view v and
     // write `view_rows` rows further down the output buffers. One camera = views[0], nviews = 1.

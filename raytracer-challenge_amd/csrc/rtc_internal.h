@@ -1,0 +1,59 @@
+// rtc_internal.h — host-side objects behind the opaque handles of include/rtc.h; shared by rtc_api.cpp
+// (one GPU) and rtc_group.cpp (row tiles across GPUs). Not part of the ABI.
+#ifndef RTC_INTERNAL_H
+#define RTC_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+
+#include <vector>
+
+#include "rtc.h"
+#include "rtc_device.h"
+
+enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2, SRC_CULL = 3, SRC_CULL2 = 4 };
+
+struct rtc_context {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    unsigned long long *d_counters = nullptr;
+    // ring of (begin, end) event pairs, one per timed k_trace launch. Created on demand, EV_CHUNK pairs
+    // at a time (a context that never renders creates none; creating all 2048 up front made
+    // rtc_context_create the slowest call of a one-frame render)
+    static constexpr uint32_t EV_RING = 1024, EV_CHUNK = 16;
+    hipEvent_t ev[EV_RING][2] = {};
+    uint32_t ev_created = 0; // pairs [0, ev_created) exist
+    uint64_t launches = 0; // render launches so far
+    uint64_t timed = 0;    // ... of which carried an event pair (ring position)
+    uint32_t time_every = 1; // rtc_context_set_timing
+    // device canvas of rtc_render (host-canvas entry point): grow-only, reused between frames
+    double *d_canvas = nullptr;
+    size_t canvas_bytes = 0;
+    int force_src = -1;   // RTC_SRC env override (experiments)
+    uint32_t tile_cap = 512;
+};
+
+struct rtc_world {
+    rtc_context *ctx = nullptr; // identity check only; never dereferenced at destroy time
+    int device = -1;
+    uint32_t n = 0;
+    DevIsect *d_isect = nullptr;
+    uint32_t *d_kind = nullptr;
+    DevShade *d_shade = nullptr;
+    DevPrim *d_prim = nullptr;
+    DevBound *d_bound = nullptr;
+    DevIsect *d_isect_s = nullptr; // Morton-sorted copies for the two-level cull
+    uint32_t *d_kind_s = nullptr;
+    DevBound *d_bound_s = nullptr;
+    uint32_t *d_orig_s = nullptr;
+    DevBound *d_gbound = nullptr;
+    DevIdEntry *d_idtab = nullptr;
+    uint32_t ngroups = 0;
+    rtc_light light{};
+    bool any_refl = false, any_refr = false;
+};
+
+
+extern "C" hipError_t rtc_launch_undeal(const void *staging, void *canvas, uint32_t nranks, uint32_t nframes, uint32_t H,
+                                        uint32_t rows_max, size_t row_bytes, hipStream_t stream);
+
+#endif

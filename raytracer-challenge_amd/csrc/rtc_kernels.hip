@@ -536,6 +536,7 @@ struct Tables {
     const DevBound *__restrict__ bound_s;
     const uint32_t *__restrict__ orig_s;
     const DevBound *__restrict__ gbound;
+    const DevIdEntry *__restrict__ idtab; // shapes in stable order of world_id (n1/n2 pass)
 };
 
 struct LdsView {
@@ -807,6 +808,17 @@ DEVI unsigned char scale255(double c) {
     return (unsigned char)(int)v; // v_cvt_i32_f64 truncates toward zero
 }
 
+// Offsets of Camera::resample's extra rays (camera.rs:84-92). The reference draws them from
+// thread_rng; the documented counter-based stand-in (include/rtc.h, rtc_camera.samples): SplitMix64 of
+// ((y*hsize + x) << 16 | draw), top 53 bits -> [0, 1).
+DEVI double resample_offset(uint32_t W, uint32_t x, uint32_t y, uint32_t draw) {
+    unsigned long long z = ((((unsigned long long)y * W + x) << 16) | draw) + 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (double)(z >> 11) * 0x1p-53;
+}
+
 // shade_hit's final combination shape.rs:692-699
 DEVI V3 combine(V3 surface, V3 reflected, V3 refracted, bool schlick, double R) {
     if (schlick) return vadd(surface, vadd(vmul(reflected, R), vmul(refracted, 1.0 - R)));
@@ -821,7 +833,7 @@ __global__ void __launch_bounds__(RTC_BLOCK_OF(REFL), (REFL ? RTC_WAVES_PER_SIMD
 k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const uint32_t *__restrict__ t_kind,
         const DevShade *__restrict__ t_shade, const DevPrim *__restrict__ t_prim, const DevBound *__restrict__ t_bound,
         const DevIsect *__restrict__ t_isect_s, const uint32_t *__restrict__ t_kind_s, const DevBound *__restrict__ t_bound_s,
-        const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound) {
+        const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound, const DevIdEntry *__restrict__ t_idtab) {
     constexpr uint32_t BLOCK = RTC_BLOCK_OF(REFL), TILE_W = RTC_TILE_W_OF(REFL);
     extern __shared__ double lds_raw[];
     __shared__ __attribute__((aligned(16))) double stage_f64[PROBE ? 1 : 8 * TILE_W * 3];      // the tile, canvas layout
@@ -831,6 +843,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     Tables T;
     T.isect = t_isect; T.kind = t_kind; T.shade = t_shade; T.prim = t_prim; T.bound = t_bound;
     T.isect_s = t_isect_s; T.kind_s = t_kind_s; T.bound_s = t_bound_s; T.orig_s = t_orig_s; T.gbound = t_gbound;
+    T.idtab = t_idtab;
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -880,7 +893,13 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
 #endif
     STAMP(0);
 
-    const uint32_t nsamples = (probe || P.samples == 1u) ? 1u : 4u;
+    // render_pixel (camera.rs:94-114): one ray, or the 4 fixed sub-samples followed — for the pixels whose
+    // samples differ by more than 0.01 from their mean — by `resample_n` more rays (Camera::resample)
+    const bool aa = !probe && P.samples != 1u;
+    uint32_t nsamples = aa ? 4u : 1u;   // grows to 4 + resample_n after sample 3 when some lane resamples
+    bool lane_resample = false;         // this lane's pixel tripped the test AND the resample is enabled
+    uint32_t c_resample = 0;            // wave-uniform: pixels that tripped the test
+    double *aa_store = reinterpret_cast<double *>(reinterpret_cast<char *>(lds_raw) + P.aa_lds_off) + threadIdx.x * 12u;
     V3 result = mk(0., 0., 0.);
 
     typedef FrameT<REFR> Frame;
@@ -900,8 +919,11 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             shared_origin = false;
         } else {
             // Camera::ray_for_pixel_offset camera.rs:64-76; sub-sample offsets camera.rs:98,102-105
-            const double xo = (nsamples == 1u) ? 0.5 : ((s & 1u) ? 0.75 : 0.25);
-            const double yo = (nsamples == 1u) ? 0.5 : ((s & 2u) ? 0.75 : 0.25);
+            double xo = 0.5, yo = 0.5;
+            if (aa) {
+                if (s < 4u) { xo = (s & 1u) ? 0.75 : 0.25; yo = (s & 2u) ? 0.75 : 0.25; }
+                else { xo = resample_offset(P.W, px, py, 2u * (s - 4u)); yo = resample_offset(P.W, px, py, 2u * (s - 4u) + 1u); }
+            }
             const double xoffset = ((double)px + xo) * Pr.pixel_size;
             const double yoffset = ((double)py + yo) * Pr.pixel_size;
             const double world_x = Pr.half_width - xoffset;
@@ -912,7 +934,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             shared_origin = true;
         }
 
-        bool tracing = traced;
+        bool tracing = traced && (s < 4u || lane_resample);
         bool first = true; // this ray is the one color_at was called with (depth 0)
         int rem = (int)P.remaining;
         int sp = 0;
@@ -1032,38 +1054,65 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 if constexpr (SRC == SRC_LDSN) any_need = __syncthreads_or(need ? 1 : 0) != 0;
                 else any_need = ballot(need) != 0ull;
                 if (any_need) {
+                    // `containers` is keyed by world_id (shape.rs:127): every entry that precedes the hit
+                    // entry in list order toggles its id. An id is present iff an odd number of its
+                    // entries precede the hit; the element standing for it is the LAST of them (the one
+                    // that pushed it back in); containers.last = the present id whose such entry is
+                    // latest in list order (max (t, shape index)). Shapes are walked grouped by id
+                    // (idtab: stable order of world_id, wave-uniform scalar loads), one class
+                    // accumulator at a time. Unique ids (World::add_shape's own numbering up to 255
+                    // shapes): a class is one shape and this is the open set of SURVEY.md App. A.6;
+                    // shared ids (the reference's u8 counter wraps, shape.rs:287,661-667): still the
+                    // literal walk. Never culled: entries with t < 0 count.
                     bool have_all = false, have_oth = false;
                     double key_all = 0., key_oth = 0.;
                     int idx_all = -1, idx_oth = -1;
-                    Bundle Ball{}; // entries with t < 0 matter here: visit every object
-                    Ball.off = true;
-                    for_each_object<SRC>(P, T, L, need, Ball, [&](int j, auto m, uint32_t kind, auto pr) {
+                    const uint32_t hid = S->world_id;
+                    uint32_t cnt_h = 0, cnt = 0;
+                    double last_t = 0.;
+                    int last_s = -1;
+                    auto fold = [&](uint32_t id) { // class `id` is complete
+                        if (id == hid) cnt_h = cnt;
+                        if (cnt & 1u) {
+                            if (!have_all || last_t > key_all || (last_t == key_all && last_s > idx_all)) { have_all = true; key_all = last_t; idx_all = last_s; }
+                            if (id != hid && (!have_oth || last_t > key_oth || (last_t == key_oth && last_s > idx_oth))) { have_oth = true; key_oth = last_t; idx_oth = last_s; }
+                        }
+                        cnt = 0;
+                        last_s = -1;
+                    };
+                    const uint32_t nobj = P.n;
+                    uint32_t cur_id = 0;
+                    for (uint32_t k = 0; k < nobj; ++k) {
+                        const DevIdEntry e = T.idtab[k];
+                        if (k > 0 && e.id != cur_id) fold(cur_id);
+                        cur_id = e.id;
                         if (need) {
+                            const int j = (int)e.index;
+                            const double *m = T.isect[j].m;
                             const V3 o = xpoint(m, ro);
                             const V3 d = xvector(m, rd);
                             double t0 = 0., t1 = 0.;
-                            const int cnt = shape_entries<false>(kind, o, d, 0., t0, t1);
-                            if (cnt > 0) {
-                                bool open;
-                                if (j == hidx) {
-                                    open = (hroot == 1);
-                                } else {
-                                    const bool p1 = t0 < best || (t0 == best && j < hidx);
-                                    const bool p2 = (cnt == 2) && (t1 < best || (t1 == best && j < hidx));
-                                    open = p1 && !p2;
-                                }
-                                if (open) {
-                                    if (!have_all || t0 > key_all || (t0 == key_all && j > idx_all)) { have_all = true; key_all = t0; idx_all = j; }
-                                    if (j != hidx && (!have_oth || t0 > key_oth || (t0 == key_oth && j > idx_oth))) { have_oth = true; key_oth = t0; idx_oth = j; }
-                                }
+                            const int cnt_e = shape_entries<false>(T.kind[j], o, d, 0., t0, t1);
+                            bool p1, p2;
+                            if (j == hidx) { p1 = (hroot == 1); p2 = false; }
+                            else {
+                                p1 = t0 < best || (t0 == best && j < hidx);
+                                p2 = t1 < best || (t1 == best && j < hidx);
+                            }
+                            p1 = p1 && cnt_e >= 1;
+                            p2 = p2 && cnt_e == 2;
+                            if (p1 || p2) {
+                                const double te = p2 ? t1 : t0; // this shape's last entry before the hit
+                                cnt += (p1 ? 1u : 0u) + (p2 ? 1u : 0u);
+                                if (last_s < 0 || te > last_t || (te == last_t && j >= last_s)) { last_t = te; last_s = j; }
                             }
                         }
-                        return true;
-                    });
+                    }
+                    if (nobj) fold(cur_id);
                     if (need) {
                         n1 = have_all ? T.shade[idx_all].refractive_index : 1.0;
-                        if (hroot == 1) n2 = have_oth ? T.shade[idx_oth].refractive_index : 1.0;
-                        else n2 = S->refractive_index;
+                        if (cnt_h & 1u) n2 = have_oth ? T.shade[idx_oth].refractive_index : 1.0; // the hit entry removes its id
+                        else n2 = S->refractive_index;                                            // the hit entry pushes its id
                     }
                 }
             }
@@ -1236,10 +1285,33 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             const uint32_t tx = wave * 8u + (lane & 7u), ty = lane >> 3; // position inside the tile
             double *slot = stage_f64 + (ty * TILE_W + tx) * 3u;
             if (!traced) result = mk(0., 0., 0.); // Canvas::new BLACK canvas.rs:37-41
-            if (nsamples > 1u) {
+            if (aa) {
+                // the slot holds Color::average_over's running sums (reds = ((0 + c0) + c1) + ..., color.rs:128-139)
+                // while a lane still collects samples, and the pixel's final colour afterwards
+                const bool collecting = s < 4u || lane_resample;
                 V3 acc = (s == 0u) ? mk(0., 0., 0.) : mk(slot[0], slot[1], slot[2]);
-                acc = vadd(acc, result);
-                if (s + 1u == nsamples) {
+                if (collecting) acc = vadd(acc, result);
+                if (s < 4u) { aa_store[s * 3u] = result.x; aa_store[s * 3u + 1u] = result.y; aa_store[s * 3u + 2u] = result.z; }
+                if (s == 3u) {
+                    // average = Color::average_over(&sample); resample if any |c - average| > 0.01 (camera.rs:106-111,
+                    // Color::distance_from color.rs:122-126: sqrt of the sum of squares)
+                    const V3 mean = mk(acc.x / 4., acc.y / 4., acc.z / 4.);
+                    bool trip = false;
+                    for (uint32_t i = 0; i < 4u; ++i) {
+                        const double dr = aa_store[i * 3u] - mean.x, dg = aa_store[i * 3u + 1u] - mean.y, db = aa_store[i * 3u + 2u] - mean.z;
+                        trip = trip || (sqrt(dr * dr + dg * dg + db * db) > 0.01);
+                    }
+                    trip = trip && traced;
+                    c_resample += popc64(ballot(trip));
+                    const auto &Pa = KP(P_arg);
+                    lane_resample = trip && Pa.resample_n != 0u;
+                    bool more;
+                    if constexpr (SRC == SRC_LDSN) more = __syncthreads_or(lane_resample ? 1 : 0) != 0; // same pass count for every wave
+                    else more = ballot(lane_resample) != 0ull;
+                    if (more) nsamples = 4u + Pa.resample_n;
+                    if (!lane_resample) acc = mean; // final: the mean of the four
+                }
+                if (s >= 4u && s + 1u == nsamples && lane_resample) { // Color::average_over(&samples) over 4 + n
                     const double l = (double)nsamples;
                     acc = mk(acc.x / l, acc.y / l, acc.z / l);
                 }
@@ -1362,6 +1434,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             if (c_reflect) atomicAdd(slot + CNT_REFLECT, (unsigned long long)c_reflect);
             if (c_refract) atomicAdd(slot + CNT_REFRACT, (unsigned long long)c_refract);
             if (npix) atomicAdd(slot + CNT_PIXELS, (unsigned long long)npix);
+            if (c_resample) atomicAdd(slot + CNT_RESAMPLE, (unsigned long long)c_resample);
 #ifdef RTC_STAMPS
             for (int i = 0; i < 7; ++i) atomicAdd(slot + CNT_STAMP0 + i, stamp_t[i + 1] - stamp_t[i]);
             for (int i = 0; i < 8; ++i) atomicAdd(slot + CNT_DIAG0 + i, (unsigned long long)diag_c[i]);
@@ -1402,6 +1475,41 @@ __global__ void k_arith(uint32_t op, const double *a, const double *b, uint32_t 
     out[i] = r;
 }
 
+// Un-deal (rtc_group_render, member 0): the gather leaves N chunks, chunk p = member p's packed bands of
+// `nframes` frames ([nframes][rows_max][row_units] units each); this puts band k of member p at image rows
+// (p + k*N)*8.. of its frame — the reference's row-major Canvas (canvas.rs:43-51). One unit = UNIT bytes
+// (16 for the f64 canvas of an even-width image), one lane per unit, 256-B contiguous per wave-instruction.
+template <class U>
+__global__ void __launch_bounds__(256) k_undeal(const U *__restrict__ staging, U *__restrict__ canvas, uint32_t nranks,
+                                                 uint32_t nframes, uint32_t H, uint32_t rows_max, uint32_t row_units) {
+    const size_t total = (size_t)nframes * H * row_units;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (size_t)gridDim.x * 256u) {
+        const uint32_t u = (uint32_t)(i % row_units);
+        const size_t fy = i / row_units;
+        const uint32_t y = (uint32_t)(fy % H), f = (uint32_t)(fy / H);
+        const uint32_t band = y / 8u, p = band % nranks, k = band / nranks;
+        canvas[i] = staging[(((size_t)p * nframes + f) * rows_max + k * 8u + (y & 7u)) * row_units + u];
+    }
+}
+
+extern "C" hipError_t rtc_launch_undeal(const void *staging, void *canvas, uint32_t nranks, uint32_t nframes, uint32_t H,
+                                        uint32_t rows_max, size_t row_bytes, hipStream_t stream) {
+    if (nframes == 0 || H == 0 || row_bytes == 0) return hipSuccess;
+    const bool a16 = row_bytes % 16u == 0 && ((size_t)staging % 16u) == 0 && ((size_t)canvas % 16u) == 0;
+    const bool a8 = row_bytes % 8u == 0 && ((size_t)staging % 8u) == 0 && ((size_t)canvas % 8u) == 0;
+    const uint32_t unit = a16 ? 16u : a8 ? 8u : 1u;
+    const size_t total = (size_t)nframes * H * (row_bytes / unit);
+    const uint32_t blocks = (uint32_t)((total + 255u) / 256u < 16384u ? (total + 255u) / 256u : 16384u);
+    typedef unsigned __attribute__((ext_vector_type(4))) u4;
+    if (unit == 16u)
+        hipLaunchKernelGGL(k_undeal<u4>, dim3(blocks), dim3(256), 0, stream, (const u4 *)staging, (u4 *)canvas, nranks, nframes, H, rows_max, (uint32_t)(row_bytes / 16u));
+    else if (unit == 8u)
+        hipLaunchKernelGGL(k_undeal<unsigned long long>, dim3(blocks), dim3(256), 0, stream, (const unsigned long long *)staging, (unsigned long long *)canvas, nranks, nframes, H, rows_max, (uint32_t)(row_bytes / 8u));
+    else
+        hipLaunchKernelGGL(k_undeal<unsigned char>, dim3(blocks), dim3(256), 0, stream, (const unsigned char *)staging, (unsigned char *)canvas, nranks, nframes, H, rows_max, (uint32_t)row_bytes);
+    return hipGetLastError();
+}
+
 // ---- launchers (called from rtc_api.cpp) --------------------------------------------------
 template <int SRC, bool REFL, bool REFR, bool PROBE>
 static hipError_t launch_kernel(const RenderParams &P, dim3 grid, size_t lds_bytes, hipStream_t stream, hipEvent_t e0,
@@ -1413,7 +1521,7 @@ static hipError_t launch_kernel(const RenderParams &P, dim3 grid, size_t lds_byt
     }
     // e0/e1 (may be NULL) receive the dispatch's own begin/end timestamps: no marker packets on the stream
     hipExtLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK_OF(REFL)), lds_bytes, stream, e0, e1, 0, P, P.isect,
-                          P.kind, P.shade, P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound);
+                          P.kind, P.shade, P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound, P.idtab);
     return hipGetLastError();
 }
 template <int SRC, bool REFL, bool REFR>

@@ -142,3 +142,25 @@ def default_scene(width: int = 11, height: int = 11):
     """camera.rs:216-224 test_render1: default world seen from (0,0,-5)."""
     cam = camera(width, height, math.pi / 2.0, Matrix.make_view_transform((0.0, 0.0, -5.0), (0.0, 0.0, 0.0), (0.0, 1.0, 0.0)))
     return World.default(), cam
+
+
+def glass_cluster(n: int = 40, width: int = 64, height: int = 48, id_modulus: int = 0, seed: int = 5):
+    """Overlapping and nested transparent spheres and cubes (every ray crosses many glass surfaces, so
+    compute_refractive's containers walk, shape.rs:115-141, decides most pixels). id_modulus > 0 numbers the
+    shapes (index + 1) % id_modulus — shapes then SHARE world ids, the situation the reference's own u8 ids
+    produce beyond 255 shapes (shape.rs:287,661-667: 256 -> 0, 257 -> 1, ...)."""
+    rng = SplitMix64(seed)
+    w = World()
+    for i in range(n):
+        r = 0.3 + 1.2 * rng.u01()
+        t = Matrix.identity().scaling(r, r * (0.6 + 0.8 * rng.u01()), r).translation(-2.5 + 5 * rng.u01(), -1 + 2.5 * rng.u01(), -1 + 4 * rng.u01())
+        m = material(color=(rng.u01(), rng.u01(), rng.u01()), diffuse=0.4, ambient=0.1, specular=0.5, shininess=80.0,
+                     transparency=0.3 + 0.6 * rng.u01(), reflective=0.3 * rng.u01() if i % 3 else 0.0,
+                     refractive_index=1.0 + 0.15 * (i % 7))
+        w.add_shape(cube(t, m) if i % 5 == 4 else sphere(t, m))
+    w.add_shape(plane(Matrix.identity().translation(0, -2.2, 0), material(color=(0.8, 0.8, 0.8), specular=0.0)))
+    if id_modulus > 0:
+        for i, sh in enumerate(w.shapes):
+            sh.world_id = (i + 1) % id_modulus
+    cam = camera(width, height, 0.9, Matrix.make_view_transform((0.0, 0.5, -7.0), (0.0, 0.0, 1.0), (0.0, 1.0, 0.0)))
+    return w, cam

@@ -596,9 +596,11 @@ def test_full_size_c5_8192(rtc, gpu, O, scenes):
     assert st["rays_reflect"] == 0
 
 
-def test_ten_thousand_spheres_lds_tiles(rtc, gpu, O, scenes):
-    """Config C3 (10 000 spheres: the object table exceeds LDS, so it is walked in tiles): a crop of
-    the 1920x1080 frame against the oracle, bit-identical hit records."""
+def test_ten_thousand_spheres_probe_rays(rtc, gpu, O, scenes):
+    """Config C3 world (10 000 spheres, two-level cull over 157 Morton groups) through rtc_color_at: the
+    PROBE instantiation k_trace<4,false,false,true> (arbitrary rays, unordered group walk), hit records
+    bit-identical to the oracle. The RENDER instantiation (ordered walk with early stop) is pinned by
+    test_full_size_c3_ten_thousand_spheres_render_path below."""
     w, cam = scenes.synthetic(10000, 1920, 1080, with_plane=False)
     dw = gpu.upload(w)
     rng = np.random.default_rng(9)
@@ -612,3 +614,70 @@ def test_ten_thousand_spheres_lds_tiles(rtc, gpu, O, scenes):
         assert np.max(np.abs(rgb[i] - orgb)) <= TIGHT_TOL
         nhit += oh.hit_index >= 0
     assert nhit > 100
+
+
+def test_full_size_c3_ten_thousand_spheres_render_path(rtc, gpu, O, scenes):
+    """Config C3 as bench.py times it: 1920x1080, 10 000 spheres, rtc_render_rows with the default
+    flags = k_trace<4,false,false,false> — the ORDERED two-level walk with early stop (take_min_key /
+    skip over 157 groups, three 64-group steps), which the probe kernel never takes. Sampled pixels
+    against the oracle (World::intersect shape.rs:677-683 + get_hit :220-232), row tiles against the full
+    frame, exact ray accounting; and on a 1920x135 band the culled render must equal plain brute force
+    (RTC_FLAG_NO_CULL -> LDS tiles, k_trace<2,...>) bit for bit, ray counts included."""
+    import torch
+    w, cam = scenes.synthetic(10000, 1920, 1080, with_plane=False)
+    st = _full_size_checks(rtc, gpu, O, w, cam, 700, 23)
+    assert st["rays_reflect"] == 0 and st["rays_refract"] == 0 and st["rays_shadow"] > 500_000
+    dw = gpu.upload(w)
+    y0, y1 = 4 * 135, 5 * 135       # the band of the frame's centre (densest part of the cloud)
+    bands, stats = [], []
+    for flags in (0, rtc.FLAG_NO_CULL):
+        b = torch.full((135, 1920, 3), -1.0, dtype=torch.float64, device="cuda:0")
+        q = torch.full((135, 1920, 3), 7, dtype=torch.uint8, device="cuda:0")
+        torch.cuda.synchronize()
+        gpu.reset_stats()
+        dw.render_rows(cam, y0, y1, b.data_ptr(), flags=flags, d_ptr8=q.data_ptr())
+        gpu.synchronize()
+        bands.append((b, q))
+        stats.append(gpu.stats())
+    assert torch.equal(bands[0][0], bands[1][0]) and torch.equal(bands[0][1], bands[1][1])
+    assert stats[0] == stats[1] and stats[0]["pixels"] == 135 * 1920
+    # the whole band against the oracle (literal sorted-list form, all host cores)
+    want, ost = O.render(w.array(), len(w), w.light, cam, mode=1, y0=y0, y1=y0 + 16, nthreads=os.cpu_count() or 1, want_stats=True)
+    got = bands[0][0][:16].cpu().numpy()
+    assert np.max(np.abs(got - want)) <= TIGHT_TOL
+    b16 = torch.zeros((16, 1920, 3), dtype=torch.float64, device="cuda:0")
+    gpu.reset_stats()
+    dw.render_rows(cam, y0, y0 + 16, b16.data_ptr())
+    gpu.synchronize()
+    assert gpu.stats() == ost
+    dw.close()
+
+
+def test_ten_thousand_spheres_lds_tiles_variant(rtc, O, scenes):
+    """SRC_LDSN at C3 size with the DEFAULT tile capacity (RTC_SRC=2, 512 objects per LDS tile, 20 tiles
+    with a workgroup barrier each — north_star's "objects staged in LDS" at a table that exceeds LDS):
+    a 1920x48 crop equals the default (culled) render bit for bit and the oracle on sampled pixels."""
+    import torch
+    w, cam = scenes.synthetic(10000, 1920, 1080, with_plane=False)
+    ctx_lds, ctx_def = make_ctx(rtc, src=2), rtc.Context(0)
+    y0, y1 = 520, 568
+    outs = []
+    for ctx in (ctx_lds, ctx_def):
+        dw = ctx.upload(w)
+        b = torch.zeros((y1 - y0, 1920, 3), dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        ctx.reset_stats()
+        dw.render_rows(cam, y0, y1, b.data_ptr())
+        ctx.synchronize()
+        outs.append((b, ctx.stats()))
+        dw.close()
+    assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+    arr = w.array()
+    rng = np.random.default_rng(31)
+    host = outs[0][0].cpu().numpy()
+    for _ in range(200):
+        x, y = int(rng.integers(0, 1920)), int(rng.integers(y0, y1))
+        want = O.color_at(arr, len(w), w.light, rtc.ray_for_pixel(cam, x, y), 5)
+        assert np.max(np.abs(host[y - y0, x] - want)) <= TIGHT_TOL, (x, y)
+    ctx_lds.close()
+    ctx_def.close()

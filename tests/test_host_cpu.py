@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(rtc):
     L = rtc.lib()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.rtc_abi_version() == 1
+    assert L.rtc_abi_version() == 2
     assert L.rtc_strerror(1) == b"Matrix is not invertable"  # transform.rs:177 panic text
 
 
@@ -265,6 +265,67 @@ def test_streaming_form_equals_literal_sorted_list_form(rtc, O, scenes):
                 c1, h1 = O.color_at(arr, len(w), w.light, r, 5, want_hit=True)
                 c2, h2 = O.color_at(arr, len(w), w.light, r, 5, streaming=True, want_hit=True)
                 assert bytes(h1) == bytes(h2) and np.array_equal(c1, c2)
+
+
+def test_streaming_form_equals_literal_with_shared_world_ids(rtc, O, scenes):
+    """compute_refractive keys its containers on world_id (shape.rs:127) and the reference's ids are a u8 that
+    wraps at 256 shapes (shape.rs:287,661-667). The streaming form (and the kernels) handle shared ids by walking
+    the shapes grouped by id; it must stay bit-identical to the literal list walk when ids collide — here with
+    ids taken modulo 3, 7 and 256 (the reference's own wrap, 300 shapes), and with unique ids."""
+    for n, mod, size in ((24, 3, (48, 36)), (40, 7, (48, 36)), (40, 0, (48, 36)), (300, 256, (32, 20))):
+        w, cam = scenes.glass_cluster(n, size[0], size[1], id_modulus=mod)
+        arr = w.array()
+        a, sa = O.render(arr, len(w), w.light, cam, mode=1, nthreads=8, streaming=False, want_stats=True)
+        b, sb = O.render(arr, len(w), w.light, cam, mode=1, nthreads=8, streaming=True, want_stats=True)
+        assert np.array_equal(a, b) and sa == sb, (n, mod)
+        assert sa["rays_refract"] > 0
+        for y in range(0, cam.vsize, 4):
+            for x in range(0, cam.hsize, 4):
+                r = rtc.ray_for_pixel(cam, x, y)
+                c1, h1 = O.color_at(arr, len(w), w.light, r, 5, want_hit=True)
+                c2, h2 = O.color_at(arr, len(w), w.light, r, 5, streaming=True, want_hit=True)
+                assert bytes(h1) == bytes(h2) and np.array_equal(c1, c2), (n, mod, x, y)
+    # shared ids really change the picture (otherwise the test above proves nothing)
+    w1, cam = scenes.glass_cluster(24, 48, 36, id_modulus=3)
+    w2, _ = scenes.glass_cluster(24, 48, 36, id_modulus=0)
+    assert not np.array_equal(O.render(w1.array(), len(w1), w1.light, cam, nthreads=8), O.render(w2.array(), len(w2), w2.light, cam, nthreads=8))
+
+
+def test_antialiasing_branch_and_resample_in_the_oracle(rtc, O, scenes):
+    """render_pixel (camera.rs:94-114): samples == 1 is one ray; EVERY other value, 0 included, averages the four
+    fixed sub-samples and tests them against the mean (> 0.01 -> resample). The resample's offsets are random in
+    the reference (thread_rng); the documented counter-based stand-in is only taken with FLAG_AA_RESAMPLE."""
+    w, _ = scenes.synthetic(30, 48, 27)
+    cams = {k: scenes.synthetic(30, 48, 27)[1] for k in (0, 1, 4, 9)}
+    for k, c in cams.items():
+        c.samples = k
+    arr = w.array()
+    one = O.render(arr, len(w), w.light, cams[1], nthreads=4)
+    r0, s0 = O.render(arr, len(w), w.light, cams[0], nthreads=4, want_stats=True)
+    r4, s4 = O.render(arr, len(w), w.light, cams[4], nthreads=4, want_stats=True)
+    assert np.array_equal(r0, r4) and not np.array_equal(r0, one)      # 0 takes the 4-sample branch too
+    assert s0["rays_primary"] == 4 * 48 * 27 and 0 < s0["pixels_resample"] < 48 * 27 and s0["pixels_resample"] == s4["pixels_resample"]
+    # resample(0) re-averages the same four samples: the flag changes nothing at samples == 0
+    r0f, s0f = O.render(arr, len(w), w.light, cams[0], nthreads=4, want_stats=True, flags=rtc.FLAG_AA_RESAMPLE)
+    assert np.array_equal(r0f, r0) and s0f == s0
+    for k in (4, 9):
+        rk, sk = O.render(arr, len(w), w.light, cams[k], nthreads=4, want_stats=True, flags=rtc.FLAG_AA_RESAMPLE)
+        assert sk["pixels_resample"] == s4["pixels_resample"]
+        assert sk["rays_primary"] == 4 * 48 * 27 + k * sk["pixels_resample"]
+        changed = (rk != r4).any(axis=2)
+        assert 0 < changed.sum() <= sk["pixels_resample"]
+        # statistical sanity of the stand-in generator: resampled pixels move towards the local mean, not away
+        assert np.abs(rk - r4).max() < 0.5
+    # the mask is deterministic: exactly the pixels whose four samples differ from their mean by > 0.01
+    trip = 0
+    off = ((0.25, 0.25), (0.75, 0.25), (0.25, 0.75), (0.75, 0.75))
+    for y in range(27):
+        for x in range(48):
+            s = np.array([O.color_at(arr, len(w), w.light, rtc.ray_for_pixel(cams[4], x, y, xo, yo), 5) for xo, yo in off])
+            red = ((0.0 + s[0]) + s[1] + s[2] + s[3]) / 4.0
+            assert np.array_equal(red, r4[y, x])
+            trip += bool((np.sqrt(((s - red) ** 2).sum(axis=1)) > 0.01).any())
+    assert trip == s4["pixels_resample"]
 
 
 def test_golden_canvases_reproduce(rtc, O, scenes):
