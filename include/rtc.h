@@ -387,13 +387,13 @@ void        rtc_group_world_destroy(rtc_group_world *w);
  * one size per call (one launch per member, as rtc_render_views). d_canvas: DEVICE memory on member 0's
  * device, nframes consecutive canvases of vsize*hsize*3 doubles (frame f at f*vsize*hsize*3); required in
  * the process that drives member 0, ignored elsewhere. d_rgb8 (may be NULL): the same frames quantised by
- * Color::scale(c, 255), nframes*vsize*hsize*3 bytes — when given, the 8-bit tiles are gathered as well.
- * `what` selects the exchange payload: */
+ * Color::scale(c, 255), nframes*vsize*hsize*3 bytes. `what` (the same value in every process of the group)
+ * selects the exchange payload, a bit set: */
 enum {
-    RTC_GATHER_F64  = 1u, /* the f64 Canvas (24 B/pixel): the path's own output                              */
-    RTC_GATHER_U8   = 2u, /* the 8-bit frame only (3 B/pixel, what every file writer of the reference consumes,
-                             canvas.rs:98-104); d_canvas is then not written                                  */
-    RTC_GATHER_NONE = 0u  /* render only: tiles stay on their GPUs (rtc_group_tile)                           */
+    RTC_GATHER_NONE = 0u, /* render only: the tiles stay on their GPUs                                         */
+    RTC_GATHER_F64  = 1u, /* the f64 Canvas (24 B/pixel), the path's own output -> d_canvas                     */
+    RTC_GATHER_U8   = 2u  /* the 8-bit frame (3 B/pixel, what every file writer of the reference consumes,
+                             canvas.rs:98-104) -> d_rgb8; RTC_GATHER_F64 | RTC_GATHER_U8 delivers both         */
 };
 rtc_status  rtc_group_render(rtc_group *g, const rtc_group_world *w, const rtc_camera *cams, uint32_t nframes,
                              uint32_t mode, uint32_t flags, uint32_t what, void *d_canvas, void *d_rgb8);

@@ -329,21 +329,17 @@ static rtc_status render_members(rtc_group *g, const rtc_group_world *w, const r
 rtc_status rtc_group_render(rtc_group *g, const rtc_group_world *w, const rtc_camera *cams, uint32_t nframes, uint32_t mode,
                             uint32_t flags, uint32_t what, void *d_canvas, void *d_rgb8) {
     if (!g || !w || !cams || w->g != g || w->w.size() != g->m.size()) return RTC_ERR_ARG;
-    if (nframes == 0 || nframes > RTC_MAX_VIEWS_PER_LAUNCH || what > RTC_GATHER_U8) return RTC_ERR_ARG;
+    if (nframes == 0 || nframes > RTC_MAX_VIEWS_PER_LAUNCH || what > (RTC_GATHER_F64 | RTC_GATHER_U8)) return RTC_ERR_ARG;
     const uint32_t W = cams[0].hsize, H = cams[0].vsize, N = g->nranks;
     if (W == 0 || H == 0) return RTC_ERR_ARG;
-    const bool f64 = what == RTC_GATHER_F64;
-    bool u8 = what == RTC_GATHER_U8 || (f64 && d_rgb8 != nullptr);
-    if (g->has_root() && ((f64 && !d_canvas) || (what == RTC_GATHER_U8 && !d_rgb8))) return RTC_ERR_ARG;
+    const bool f64 = (what & RTC_GATHER_F64) != 0, u8 = (what & RTC_GATHER_U8) != 0;
+    if (g->has_root() && ((f64 && !d_canvas) || (u8 && !d_rgb8))) return RTC_ERR_ARG;
     const uint32_t rows = packed_rows(H, N);
     const size_t row_bytes = (size_t)W * 3u * sizeof(double), row8 = (size_t)W * 3u;
     const size_t tile_bytes = (size_t)nframes * rows * row_bytes, tile8_bytes = (size_t)nframes * rows * row8;
     const int b = (int)(g->batches & 1u);
-    // with one process per GPU only member 0's process sees d_rgb8: the 8-bit tiles travel iff `what` says so
-    const bool want8 = what == RTC_GATHER_U8 || (g->in_process && u8);
-    u8 = want8;
     {
-        const rtc_status st = render_members(g, w, cams, nframes, mode, flags, want8, b);
+        const rtc_status st = render_members(g, w, cams, nframes, mode, flags, u8, b);
         if (st != RTC_OK) return st;
     }
     ++g->batches;
@@ -401,7 +397,7 @@ rtc_status rtc_group_render(rtc_group *g, const rtc_group_world *w, const rtc_ca
         Member &root = g->m[0];
         HIP_TRY(hipSetDevice(root.device));
         if (f64) HIP_TRY(rtc_launch_undeal(g->staging, d_canvas, N, nframes, H, rows, row_bytes, root.s_comm));
-        if (u8 && d_rgb8) HIP_TRY(rtc_launch_undeal(g->staging8, d_rgb8, N, nframes, H, rows, row8, root.s_comm));
+        if (u8) HIP_TRY(rtc_launch_undeal(g->staging8, d_rgb8, N, nframes, H, rows, row8, root.s_comm));
     }
     for (Member &mb : g->m) {
         HIP_TRY(hipSetDevice(mb.device));

@@ -54,7 +54,7 @@ def test_group_render_assembles_the_single_gpu_frame(rtc, gpu, scenes, kind):
     frame8 = torch.full((3, H, W, 3), 9, dtype=torch.uint8, device="cuda:0")
     torch.cuda.synchronize()
     g.reset_stats()
-    gw.render(cams, rtc.GATHER_F64, canvas.data_ptr(), frame8.data_ptr())
+    gw.render(cams, rtc.GATHER_F64 | rtc.GATHER_U8, canvas.data_ptr(), frame8.data_ptr())
     g.synchronize()
     assert g.stats() == total
     ch, qh = canvas.cpu().numpy(), frame8.cpu().numpy()
