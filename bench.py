@@ -2,20 +2,27 @@
 """bench.py — the hot path's headline metric on MI355X.
 
 Metric (BASELINE.json): Mrays/sec (primary+shadow), 1920x1080 x 100 spheres; 1/2/4/8 MI355X.
-A step = one frame: Camera::render_async over the synthetic N-sphere scene (SURVEY.md §8d,
-SplitMix64 seed 13) with the World and the Canvas tile resident in HBM. One launch renders 8
-consecutive frames (rtc_render_views; --views-per-launch 1 makes a launch a frame). With --gpus N
-the frame is row-tiled (8-row bands dealt round-robin, rank r renders bands r, r+N, ...), the tiles
-of 32 frames are gathered to rank 0 with one RCCL gather and un-dealt there — total work is fixed,
-so scaling is "strong". DESIGN.md §6/§7 explain every one of these choices with measurements.
+A step = one frame: Camera::render_async (camera.rs:144-160) over a synthetic scene (SURVEY.md §8d,
+SplitMix64 seed 13) with the World resident in HBM and the f64 Canvas left in HBM. One launch renders
+`--views-per-launch` (default 8) consecutive frames (rtc_render_views).
 
-Prints ONE JSON line on rank 0. `roofline` is the HBM view the north star asks for (algorithmic
-bytes / kernel time vs 8 TB/s). `valu_roofline` prices the reference's brute-force arithmetic
-(54 f64 flop per ray x sphere) against 39.3 T f64-instr/s (FMA contraction off); the
-culled kernel skips most of that arithmetic, so this figure can exceed 1 — it is the algorithmic
-rate delivered, not a hardware utilisation.
-`cpu_baseline` times the CPU oracle (a port of the Rust path; the Rust sources cannot be built
-here) on the host cores, rank 0, N=1 only.
+--gpus N (one process per GPU, torch.distributed.run): the frame is row-tiled behind the C-ABI
+(rtc_group, include/rtc.h) — 8-row bands dealt round-robin, member r renders bands r, r+N, ..., the
+f64 tiles are gathered to member 0 with ONE RCCL gather per batch (ncclGather over xGMI, issued by
+librtc.so itself) and un-dealt there into the reference's row-major Canvas. Total work is fixed, so
+scaling is "strong". The headline value for N > 1 is measured WITH the f64 Canvas exchange (the path's
+own output, 24 B/pixel); the same run then repeats a shorter timed loop with the 8-bit frame
+(Color::scale, 3 B/pixel) and with no exchange, reported as labelled secondary records.
+
+Prints ONE JSON line on rank 0:
+  roofline      HBM view: algorithmic bytes of one launch / that launch's duration (HIP events on the
+                launch stream) vs 8 TB/s; `traffic` = HBM bytes per launch from the committed PMC profile
+  valu_issue    the figure that actually binds: VALU wave-instructions (PMC) x 4 cycles over the SIMD-cycles
+                the kernel had — an issue-slot utilisation, always <= 1
+  single_view   the drop-in launch shape: ONE camera per launch (Camera::render_async is one camera per call)
+  dropin        N = 1: the host-canvas call a Rust caller makes — context create, world upload, rtc_render
+                into pageable / registered / page-locked canvases (PCIe-inclusive; never `value`)
+  cpu_baseline  the CPU oracle (a C port of the Rust path) on the host cores, N = 1 only.
 """
 from __future__ import annotations
 
@@ -30,16 +37,24 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path[:0] = [str(ROOT), str(ROOT / "oracle")]
 
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+SIMDS, CLOCK_HZ = 1024, 2.4e9   # 256 CUs x 4 SIMDs, max clock (MI355X_MICROARCH.md chip table)
+
+# BASELINE.json configs. `ns` = the point the metric is quoted on.
+WORKLOADS = {
+    "ns": dict(width=1920, height=1080, spheres=100, desc="north star: 1920x1080, 100 spheres + checker floor plane"),
+    "c2": dict(width=1920, height=1080, scene="test7", desc="C2: 1920x1080, the reference's test7 scene (main.rs:204-251), 3 spheres + 1 plane"),
+    "c3": dict(width=1920, height=1080, spheres=10000, no_plane=True, desc="C3: 1920x1080, 10 000 random spheres"),
+    "c4": dict(width=4096, height=4096, spheres=100, reflective=True, desc="C4: 4096x4096, 100 spheres + floor, reflective depth 5"),
+    "c5": dict(width=8192, height=8192, spheres=1000, desc="C5: 8192x8192, 1000 spheres + checker floor plane"),
+}
+
+
 def baseline_metric():
-    """BASELINE.json's metric string (the headline the line is checked against)."""
     try:
         return json.loads((ROOT / "BASELINE.json").read_text())["metric"]
     except Exception:
-        return "Mrays/sec (primary+shadow), 1920\u00d71080 \u00d7 100 spheres; 1/2/4/8 MI355X"
-
-
-HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-FP64_PEAK_TINSTR = 39.3      # 78.6 TFLOP/s FP64 vector counts FMA as 2; contraction is off here
+        return "Mrays/sec (primary+shadow), 1920×1080 × 100 spheres; 1/2/4/8 MI355X"
 
 
 def parse():
@@ -47,47 +62,52 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--spheres", type=int, default=100)
+    ap.add_argument("--workload", default="ns", choices=sorted(WORKLOADS), help="BASELINE.json configuration (default: the north-star point)")
+    ap.add_argument("--width", type=int, default=0)
+    ap.add_argument("--height", type=int, default=0)
+    ap.add_argument("--spheres", type=int, default=-1)
     ap.add_argument("--no-plane", action="store_true")
     ap.add_argument("--reflective", action="store_true")
+    ap.add_argument("--views-per-launch", type=int, default=8,
+                    help="consecutive frames one launch renders (rtc_render_views; this static benchmark repeats one camera, "
+                         "an animation passes its camera path); clamped so that a launch's canvases stay within ~4 GB")
+    ap.add_argument("--exchange", default="f64", choices=["f64", "u8", "none"],
+                    help="N > 1: what member 0 collects in the MEASURED run: the f64 Canvas (default, the path's output), "
+                         "the 8-bit frame, or nothing. The other two are reported as secondary records")
+    ap.add_argument("--force-group", action="store_true",
+                    help="take the multi-GPU code path (rtc_group in rank mode, RCCL communicator, gather, un-deal) with one rank")
+    ap.add_argument("--time-every", type=int, default=1, help="HIP-event pair on every n-th launch (1 = all)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (bounded sample)")
-    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
-                    help="gloo is a rehearsal aid for boxes with fewer GPUs than ranks (tiles hop through host memory)")
-    ap.add_argument("--no-overlap", action="store_true", help="wait for each gather before rendering the next frame")
-    ap.add_argument("--force-dist", action="store_true",
-                    help="take the distributed code path (process group, gather, reductions) even with one rank: "
-                         "exercises RCCL on a 1-GPU box")
-    ap.add_argument("--gather", default="u8", choices=["u8", "f64"],
-                    help="what rank 0 collects: the 8-bit frame (Color::scale, 3 B/pixel - what every file writer of the "
-                         "reference consumes) or the raw f64 canvas (24 B/pixel; xGMI-ingest bound at this frame size)")
-    ap.add_argument("--frames-per-exchange", type=int, default=32,
-                    help="N>1: how many frames' tiles each rank sends per RCCL gather (1 = a gather per frame)")
-    ap.add_argument("--streams", type=int, default=0,
-                    help="frames in flight: consecutive frames are launched round-robin on this many HIP streams, so a "
-                         "launch that cannot fill the chip (a rank's 1/N of the frame) overlaps the next one. "
-                         "0 = 1 stream for the single-GPU run (clean per-kernel timing), 2 for N > 1 "
-                         "(if two are measured to run side by side)")
-    ap.add_argument("--pipelined-probe", action="store_true",
-                    help="single GPU: after the measured run, also time the same frames with two in flight on two HIP "
-                         "streams and report it as the informational `pipelined` block (off by default so that a "
-                         "profiler sees only the measured run's launches)")
-    ap.add_argument("--views-per-launch", type=int, default=0,
-                    help="how many consecutive frames one launch renders (rtc_render_views; every frame of this static "
-                         "benchmark has the same camera, an animation would pass its camera path). Default 8: the "
-                         "launch overheads, the ramp-up and the tail of a launch are paid once per 8 frames, and a "
-                         "rank's launch stays a whole frame's worth of work at 8 GPUs. 1 = a launch is a frame. "
-                         "Needs --tiling bands when the exchange is on")
-    ap.add_argument("--time-every", type=int, default=0,
-                    help="take the kernel duration on every n-th launch of each stream (a launch's start/stop events "
-                         "cost ~9 us of host and ~5 us of GPU time). 0 = every launch on one GPU (what rocprofv3's "
-                         "kernel trace is compared with), every 8th for N > 1 (launch-bound)")
-    ap.add_argument("--tiling", default="bands", choices=["bands", "rows"],
-                    help="how the rows are cut across ranks: 8-row bands dealt round-robin (even work per rank; rank 0 "
-                         "un-deals them after the gather) or one contiguous range of rows per rank")
-    return ap.parse_args()
+    ap.add_argument("--no-dropin", action="store_true", help="skip the host-canvas (PCIe-inclusive) drop-in measurements")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the single-view / other-exchange secondary runs")
+    ap.add_argument("--lean", action="store_true", help="= --no-cpu-baseline --no-dropin --no-secondary (profiling runs)")
+    a = ap.parse_args()
+    if a.lean:
+        a.no_cpu_baseline = a.no_dropin = a.no_secondary = True
+    return a
+
+
+def build_scene(args, scenes):
+    cfg = dict(WORKLOADS[args.workload])
+    if args.width:
+        cfg["width"] = args.width
+    if args.height:
+        cfg["height"] = args.height
+    custom = args.spheres >= 0 or args.no_plane or args.reflective
+    if custom:
+        cfg = dict(width=cfg["width"], height=cfg["height"], spheres=args.spheres if args.spheres >= 0 else cfg.get("spheres", 100),
+                   no_plane=args.no_plane, reflective=args.reflective)
+    W, H = cfg["width"], cfg["height"]
+    if cfg.get("scene") == "test7":
+        world, cam = scenes.test7(W, H)
+        desc = f"{W}x{H}, reference scene test7 (3 spheres + 1 plane)"
+    else:
+        world, cam = scenes.synthetic(cfg["spheres"], W, H, with_plane=not cfg.get("no_plane", False), reflective=cfg.get("reflective", False))
+        desc = (f"{W}x{H}, {cfg['spheres']} spheres" + ("" if cfg.get("no_plane") else " + checker floor plane") +
+                (", reflective depth 5" if cfg.get("reflective") else ""))
+    key = args.workload if not (custom or args.width or args.height) else "custom"
+    return world, cam, key, desc + ", 1 point light, render_async, SplitMix64 seed 13"
 
 
 def algorithmic_bytes(W, rows, world):
@@ -97,24 +117,50 @@ def algorithmic_bytes(W, rows, world):
     return 24 * W * rows + 400 * n + 128 * n_pat + 200
 
 
-def measured_traffic(workload_prefix, frames_per_launch=1):
-    """HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 cannot be run
-    from inside the timed process); newest summary whose workload matches, else None."""
+def committed_profile(key):
+    """Newest PMC summary under profiles/ for this workload (rocprofv3 cannot run inside the timed process):
+    per-FRAME HBM traffic and VALU wave-instructions of the dominant kernel."""
     best = None
     for f in sorted((ROOT / "profiles").glob("r*_pmc.json")):
         try:
             d = json.loads(f.read_text())
-            if workload_prefix.startswith(d.get("workload", "\0")) and d.get("frames_per_launch", 1) == frames_per_launch:
-                best = (d["hbm_traffic"]["traffic_bytes"], f"profiles/{f.name}")
+            if d.get("workload_key") == key and "per_frame" in d:
+                best = (d["per_frame"], f"profiles/{f.name}")
         except Exception:
             continue
     return best
 
 
-def algorithmic_flops(world, rays_total, hits):
-    """54 f64 flop per (ray, sphere), 33 per (ray, plane), ~200 per hit."""
-    per_ray = sum(54 if s.kind == 0 else 33 if s.kind == 1 else 60 for s in world.shapes)
-    return rays_total * per_ray + hits * 200
+class FrameQueue:
+    """Frames are handed over one at a time (a step = a frame); a launch goes out every V frames."""
+
+    def __init__(self, V, launch):
+        self.V, self.launch, self.pending, self.sizes = V, launch, 0, []
+
+    def step(self):
+        self.pending += 1
+        if self.pending == self.V:
+            self.flush()
+
+    def flush(self):
+        if self.pending:
+            self.launch(self.pending)
+            self.sizes.append(self.pending)
+            self.pending = 0
+
+
+def timed(fn_step, fn_flush, fn_sync, steps, barrier=None):
+    if barrier:
+        barrier()
+    fn_sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn_step()
+    fn_flush()
+    fn_sync()
+    if barrier:
+        barrier()
+    return time.perf_counter() - t0
 
 
 def main():
@@ -126,365 +172,306 @@ def main():
     world_size = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world_size:
-        if world_size == 1 and args.gpus > 1:
-            sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
+    if args.gpus != world_size and world_size == 1 and args.gpus > 1:
+        sys.exit(f"--gpus {args.gpus} needs `python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py ...`")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs an MI355X: no HIP device is visible (there is no CPU fallback for the render path)")
-    dev_index = local_rank % torch.cuda.device_count()  # == local_rank on a full node
+    dev_index = local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
-    gloo = args.dist_backend == "gloo"
-    dist_on = world_size > 1 or args.force_dist
-    if args.force_dist and world_size == 1:
+    grouped = world_size > 1 or args.force_group
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-    if dist_on:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if gloo:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=dev)  # nccl == RCCL on ROCm
+        dist.init_process_group("nccl", device_id=dev)   # nccl == RCCL on ROCm: barrier + reductions of the report
 
     from _bootstrap import package
     rtc = package()
     scenes = importlib.import_module(rtc.__name__ + ".scenes")
-    tiles = importlib.import_module(rtc.__name__ + ".tiles")
+    world, cam, wkey, wdesc = build_scene(args, scenes)
+    W, H = cam.hsize, cam.vsize
+    N = world_size
+    nbands = -(-H // 8)
+    rows_max = -(-nbands // N) * 8                      # rows of one member's packed tile (rtc_group)
+    rows_mine = sum(min(8, H - 8 * b) for b in range(rank, nbands, N))
+    V = max(1, min(args.views_per_launch, 8, int(4e9 // (rows_max * W * 24))))
+    cams = {n_: (type(cam) * n_)(*([cam] * n_)) for n_ in range(1, V + 1)}
+    barrier = (lambda: dist.barrier()) if grouped else None
 
-    W, H = args.width, args.height
-    world, cam = scenes.synthetic(args.spheres, W, H, with_plane=not args.no_plane, reflective=args.reflective)
-    banded = args.tiling == "bands" and (world_size > 1 or args.force_dist)
-    y0, y1 = tiles.row_range(H, world_size, rank)
-    V = args.views_per_launch if args.views_per_launch > 0 else (8 if (banded or not dist_on) else 1)
-    V = max(1, min(V, 8))
-    if V > 1 and dist_on and not banded:
-        sys.exit("--views-per-launch > 1 needs --tiling bands when the exchange is on")
-    rows_max = tiles.packed_rows(H, world_size) if (banded or V > 1) else tiles.rows_per_rank(H, world_size)
-    V = max(1, min(V, int(4e9 // (rows_max * W * 24))))     # a launch's V f64 tiles stay within ~4 GB (C5-sized frames: V = 2)
-    rows_mine = (sum(min(8, H - 8 * b) for b in tiles.bands_of_rank(H, world_size, rank)) if banded else y1 - y0)
+    if grouped:
+        uid = torch.zeros(rtc.GROUP_ID_BYTES, dtype=torch.uint8, device=dev)
+        if rank == 0:
+            uid.copy_(torch.tensor(list(rtc.group_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        group = rtc.Group(device=dev_index, nranks=N, rank=rank, uid=bytes(uid.cpu().tolist()))
+        ctx = group.contexts[0]
+        gworld = group.upload(world)
+        # member 0's destination: two batches of V canvases (a consumer reads batch j while batch j+1 is assembled)
+        canv = [torch.zeros((V, H, W, 3), dtype=torch.float64, device=dev) for _ in range(2)] if rank == 0 else [None, None]
+        canv8 = [torch.zeros((V, H, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)] if rank == 0 else [None, None]
+        torch.cuda.synchronize(dev)
+        state = {"batch": 0, "what": {"f64": rtc.GATHER_F64, "u8": rtc.GATHER_U8, "none": rtc.GATHER_NONE}[args.exchange]}
 
-    # Stream 0 is torch's current stream (RCCL orders against it); further streams carry every S-th
-    # frame. One context (= one stream, one event ring, one counter block) per stream, the World uploaded
-    # into each (it is ~50 KB).
-    S = args.streams if args.streams > 0 else (2 if dist_on else 1)
-    stream = torch.cuda.current_stream(dev)
-    # HIP multiplexes streams onto 4 hardware queues (GPU_MAX_HW_QUEUES; raising it made things slower
-    # here): a second render stream easily lands on the queue of the first and the two then serialise.
-    # So create a few candidates and MEASURE which of them run beside stream 0 (pick_overlapping_streams).
-    pool = 1 if S == 1 else S + 3
-    streams = [stream] + [torch.cuda.Stream(dev) for _ in range(pool - 1)]
-    ctxs = [rtc.Context(dev_index, stream=st_.cuda_stream) for st_ in streams]
-    dworlds = [c.upload(world) for c in ctxs]
-    ctx, dworld = ctxs[0], dworlds[0]
-    everything = list(zip(dworlds, ctxs))   # closed at the end, whichever streams end up in use
-    # The exchange: K frames' tiles per rank go out in ONE gather (fewer, larger collectives: a gather
-    # costs ~35 us of fixed enqueue / cross-stream work, half a frame at this size; one rank's 1/8 of the
-    # frame: 20.4 us per frame at K = 8, 16.2 at 16, 14.3 at 32, 13.5 at 64, 12.9 without any exchange). Two batch buffers:
-    # the RCCL gather of batch j runs (on RCCL's own stream) while batch j+1 renders; a buffer is reused
-    # only after the gather that reads or fills it has completed.
-    K = max(1, args.frames_per_exchange) if dist_on else S * V   # frames in flight never share an output slot
-    if dist_on:                     # a batch keeps K f64 tiles (+ their 8-bit frames) per buffer: stay within ~2 GB
-        K = max(1, min(K, int(2e9 // (rows_max * W * 24))))
-        V = min(V, K)
-        K -= K % V                  # whole launches per batch
-    nbuf = 1 if (not dist_on or args.no_overlap) else 2
-    gdev = torch.device("cpu") if gloo else dev
-    # every step renders the f64 canvas tile (resident in HBM, Canvas::get_pixel semantics) AND its
-    # 8-bit quantisation; the exchange moves one of the two
-    gdtype = torch.uint8 if args.gather == "u8" else torch.float64
-    tile_bufs = [torch.zeros((K, rows_max, W, 3), dtype=torch.float64, device=dev) for _ in range(nbuf)]
-    tile8_bufs = [torch.zeros((K, rows_max, W, 3), dtype=torch.uint8, device=dev) for _ in range(nbuf)]
-    root = rank == 0 and dist_on
-    # gather destination on rank 0: rank-major, (N, K, rows_max, W, 3) flattened over the first three axes
-    canvases = [torch.empty((world_size * K * rows_max, W, 3), dtype=gdtype, device=gdev) if root else None for _ in range(nbuf)]
-    bands = [tiles.band_views(c, world_size) if c is not None else None for c in canvases]
-    # rank 0 turns what the gather delivers into K row-major frames with one strided device copy
-    # (not needed when K == 1 and the ranks own contiguous rows: the gather then lands every tile in place)
-    need_copy = root and (banded or K > 1)
-    frames = [torch.empty((K, world_size * rows_max, W, 3), dtype=gdtype, device=gdev) for _ in range(nbuf)] if need_copy else None
-    if need_copy:
-        per = rows_max // tiles.BAND_ROWS
-        if banded:   # (N, K, per, 8) -> (K, per, N, 8): frame-major, bands back in image order
-            undeal = [(f.view(K, per, world_size, tiles.BAND_ROWS, W, 3),
-                       c.view(world_size, K, per, tiles.BAND_ROWS, W, 3).permute(1, 2, 0, 3, 4, 5)) for c, f in zip(canvases, frames)]
-        else:        # (N, K, rows) -> (K, N, rows)
-            undeal = [(f.view(K, world_size, rows_max, W, 3), c.view(world_size, K, rows_max, W, 3).permute(1, 0, 2, 3, 4))
-                      for c, f in zip(canvases, frames)]
-    pending = [None] * nbuf
-    state = {"k": 0, "pend": 0, "launches": 0}
-    cam_arrays = {n_: (type(cam) * n_)(*([cam] * n_)) for n_ in range(1, V + 1)}   # the frames' cameras, per launch size
+        def launch(n):
+            b = state["batch"] & 1
+            state["batch"] += 1
+            gworld.render(cams[n], state["what"], canv[b].data_ptr() if rank == 0 else None,
+                          canv8[b].data_ptr() if rank == 0 else None)
+        sync = group.synchronize
+        stats, reset_stats = group.stats, group.reset_stats
+    else:
+        ctx = rtc.Context(dev_index, stream=torch.cuda.current_stream(dev).cuda_stream)
+        dworld = ctx.upload(world)
+        tile = torch.zeros((V * rows_max, W, 3), dtype=torch.float64, device=dev)
+        tile8 = torch.zeros((V * rows_max, W, 3), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)
 
-    def step():
-        k = state["k"]
-        state["k"] = k + 1
-        slot, b = k % K, (k // K) % nbuf
-        if slot == 0:
-            if pending[b] is not None:
-                finish(b)           # stream 0 waits for the gather that last used batch buffer b ...
-            for st_ in streams[1:]:
-                st_.wait_stream(stream)   # ... and the other streams wait for stream 0 (once per batch)
-        state["pend"] += 1
-        if state["pend"] == V or slot == K - 1:
-            launch(b, slot)
-        if dist_on and slot == K - 1:
-            exchange(b)
+        def launch(n):
+            dworld.render_views(cams[n], 0, 1, tile.data_ptr(), rows_max, rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
+        sync = ctx.synchronize
+        stats, reset_stats = ctx.stats, ctx.reset_stats
 
-    def launch(b, last_slot):
-        """One launch for the frames accumulated since the last one (V of them, fewer at a batch's end)."""
-        cnt = state["pend"]
-        if cnt == 0:
-            return
-        state["pend"] = 0
-        lane = state["launches"] % len(dworlds)
-        state["launches"] += 1
-        # single GPU: every stream owns V output slots (frames on one stream are ordered); with the exchange
-        # on, a frame's slot is its place in the batch
-        first = last_slot - cnt + 1 if dist_on else lane * V
-        tile, tile8 = tile_bufs[b][first], tile8_bufs[b][first]
-        if V == 1:
-            render_on(lane, tile, tile8)
-        else:
-            dworlds[lane].render_views(cam_arrays[cnt], rank if banded else 0, world_size if banded else 1, tile.data_ptr(),
-                                       rows_max, rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
-
-    # rank 0's un-deal copy (a batch's worth of frames, read + written once) runs on its own stream so that
-    # rank 0's renders do not queue behind it: it depends on the gather only. (Per batch, not per frame: the
-    # extra host calls no longer matter.)
-    copy_stream = torch.cuda.Stream(dev) if (need_copy and not gloo) else None
-
-    def exchange(b):
-        for st_ in streams[1:]:
-            stream.wait_stream(st_)       # the gather (ordered after stream 0) needs every frame of the batch
-        if copy_stream is not None:
-            stream.wait_stream(copy_stream)   # ... and overwrites canvases[b]: its last un-deal copy must be done
-        src = (tile8_bufs[b] if args.gather == "u8" else tile_bufs[b]).view(K * rows_max, W, 3)
-        src = src.cpu() if gloo else src
-        work = tiles.gather_tiles(src, canvases[b], world_size, rank, async_op=not args.no_overlap, bands=bands[b])
-        if work is not None:
-            pending[b] = work
-        elif need_copy:
-            undeal[b][0].copy_(undeal[b][1])
-
-    def finish(b):
-        work, pending[b] = pending[b], None
-        work.wait()                       # stream 0: the batch's tile buffer is rendered into next
-        if need_copy:
-            if copy_stream is not None:
-                with torch.cuda.stream(copy_stream):
-                    work.wait()
-                    undeal[b][0].copy_(undeal[b][1])
-            else:
-                undeal[b][0].copy_(undeal[b][1])
-
-    def render_on(i, tile, tile8):
-        if banded:
-            dworlds[i].render_bands(cam, rank, world_size, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
-        else:
-            dworlds[i].render_rows(cam, y0, y1, tile.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=tile8.data_ptr())
-
-    def pick_overlapping_streams(S=S):
-        """Keep S of the candidate streams: stream 0 plus those whose launches really run beside
-        stream 0's (two streams that share a hardware queue serialise). Measured, not assumed: pairs of
-        this rank's own launches on (stream 0, candidate) against pairs on stream 0 alone."""
-        if S == 1 or len(streams) == 1:
-            return 1
-        ta = [torch.zeros((rows_max, W, 3), dtype=torch.float64, device=dev) for _ in range(2)]
-        tq = [torch.zeros((rows_max, W, 3), dtype=torch.uint8, device=dev) for _ in range(2)]
-
-        def pairs2(a, b, reps=24):
-            best = float("inf")
-            for _ in range(3):
-                torch.cuda.synchronize(dev)
-                t = time.perf_counter()
-                for _ in range(reps):
-                    render_on(a, ta[0], tq[0])
-                    render_on(b, ta[1], tq[1])
-                torch.cuda.synchronize(dev)
-                best = min(best, time.perf_counter() - t)
-            return best
-
-        pairs2(0, 0)
-        serial = pairs2(0, 0)
-        ratio0 = {j: pairs2(0, j) / serial for j in range(1, len(streams))}
-        keep = [0]
-        for j in sorted(ratio0, key=ratio0.get):        # greedy: a stream joins if it overlaps with every one kept so far
-            if len(keep) == S:
-                break
-            if ratio0[j] < 0.95 and all(pairs2(x, j) / serial < 0.95 for x in keep[1:]):
-                keep.append(j)
-        if os.environ.get("RTC_BENCH_DEBUG"):
-            print(f"rank {rank}: serial pair {serial * 1e3:.3f} ms; candidate/serial vs stream 0: "
-                  + ", ".join(f"{j}:{r:.2f}" for j, r in sorted(ratio0.items())) + f"; kept {keep}", file=sys.stderr)
-        streams[:] = [streams[j] for j in keep]
-        ctxs[:] = [ctxs[j] for j in keep]
-        dworlds[:] = [dworlds[j] for j in keep]
-        return len(keep)
-
-    def drain():
-        k = state["k"]
-        state["last"] = k - 1
-        if state["pend"]:            # frames handed to step() but not launched yet
-            launch(((k - 1) // K) % nbuf, (k - 1) % K)
-        if k % K != 0:              # a partly filled batch: exchange it as it is (the unused slots carry old frames)
-            if dist_on:
-                exchange(((k - 1) // K) % nbuf)
-            state["k"] = k + (K - k % K)   # the next frame starts a batch (and a launch)
-        for b in range(nbuf):
-            if pending[b] is not None:
-                finish(b)
-
-    for _ in range(V):              # first-use costs (code object load, communicator set-up) never land in the
-        step()                      # timed region, whatever --warmup is: one launch of the usual size ...
-    drain()                         # ... and, with the exchange on, the (partly filled) batch it belongs to
-    torch.cuda.synchronize(dev)
-    in_flight = pick_overlapping_streams()   # streams (= frames in flight) actually used from here on
+    q = FrameQueue(V, launch)
+    # first-use costs (code object load, communicator set-up) never land in the timed region
+    for _ in range(V):
+        q.step()
+    q.flush()
+    sync()
     for _ in range(args.warmup):
-        step()
-    drain()
-    time_every = args.time_every if args.time_every > 0 else (8 if dist_on else 1)
-    launches_before = state["launches"]
-    for c in ctxs:
-        c.reset_stats()
-        c.set_timing(time_every)   # from here on: the timed region's launches only
-    # kernel duration: every launch carries its own pair of HIP events on the launch stream
-    # (hipExtLaunchKernel start/stop events inside rtc_render_rows, read back after the timed region),
-    # on every --time-every-th launch
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step()
-    drain()
-    torch.cuda.synchronize(dev)
-    if dist_on:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
+        q.step()
+    q.flush()
+    sync()
+    reset_stats()
+    ctx.set_timing(args.time_every)
+    q.sizes.clear()
+    elapsed = timed(q.step, q.flush, sync, args.steps, barrier)
+    st = stats()
+    sizes = list(q.sizes)
+    times = ctx.kernel_times_ms(1024)
+    # launches that carried an event pair: every time_every-th, in order
+    timed_sizes = sizes[::args.time_every][-len(times):] if len(times) else []
+    full = [t for t, n_ in zip(times, timed_sizes) if n_ == V]
+    if full:
+        kernel_ms, kernel_frames = float(np.mean(full)), V
+    elif len(times):
+        kernel_ms, kernel_frames = float(times[-1]), timed_sizes[-1]
+    else:
+        kernel_ms, kernel_frames = 0.0, V
+    kernel_ms_per_frame = float(np.sum(times) / max(1, sum(timed_sizes))) if len(times) else 0.0
 
-    st = {}
-    for c in ctxs:
-        for key, v in c.stats().items():
-            st[key] = st.get(key, 0) + v
-    # the timed steps (the newest 1024 per stream if more)
-    times = np.concatenate([c.kernel_times_ms(1024) for c in ctxs])   # the sampled launches of the timed region
-    kernel_ms = float(times.mean()) if len(times) else 0.0
-    last_ms = float(times[-1]) if len(times) else 0.0
-    # Single GPU, for information only (the line's value / roofline stay those of the one-stream run, whose
-    # per-kernel durations are what rocprofv3 shows): the same frames with two in flight on two HIP streams,
-    # so that one launch's tail and the next one's ramp-up overlap.
-    pipelined = None
-    if not dist_on and S == 1 and args.pipelined_probe:
-        extra = [torch.cuda.Stream(dev) for _ in range(4)]
-        streams.extend(extra)
-        ctxs.extend(rtc.Context(dev_index, stream=st_.cuda_stream) for st_ in extra)
-        dworlds.extend(c.upload(world) for c in ctxs[1:])
-        everything.extend(zip(dworlds[1:], ctxs[1:]))
-        if pick_overlapping_streams(2) == 2:
-            outs = [(torch.zeros((rows_max, W, 3), dtype=torch.float64, device=dev), torch.zeros((rows_max, W, 3), dtype=torch.uint8, device=dev))
-                    for _ in range(2)]
-            for k in range(args.warmup):
-                render_on(k % 2, *outs[k % 2])
-            torch.cuda.synchronize(dev)
-            t1 = time.perf_counter()
-            for k in range(args.steps):
-                render_on(k % 2, *outs[k % 2])
-            torch.cuda.synchronize(dev)
-            dt = time.perf_counter() - t1
-            pipelined = {"streams": 2, "ms_per_step": round(dt / max(1, args.steps) * 1e3, 4),
-                         "value": round((st["rays_primary"] + st["rays_shadow"]) / dt / 1e6, 3), "unit": "Mrays/s",
-                         "note": "two frames in flight on two HIP streams (bench.py --streams 2 makes this the measured run)"}
-    # outside the timed region: the last frame rank 0 assembled from the gathered tiles must be the
-    # frame one GPU renders on its own, bit for bit
+    # ---- secondary records (outside the headline's timed region; every rank runs the same sequence)
+    secondary = {}
+    if not args.no_secondary:
+        n2 = max(V, min(args.steps, 64))
+        if grouped:
+            for name, what in (("f64", rtc.GATHER_F64), ("u8", rtc.GATHER_U8), ("none", rtc.GATHER_NONE)):
+                if name == args.exchange:
+                    continue
+                state["what"] = what
+                for _ in range(V):
+                    q.step()
+                q.flush()
+                sync()
+                reset_stats()
+                dt = timed(q.step, q.flush, sync, n2, barrier)
+                s2 = stats()
+                secondary["exchange_" + name] = (dt, s2["rays_primary"] + s2["rays_shadow"], n2)
+            state["what"] = {"f64": rtc.GATHER_F64, "u8": rtc.GATHER_U8, "none": rtc.GATHER_NONE}[args.exchange]
+        else:
+            q1 = FrameQueue(1, launch)     # ONE camera per launch: the shape of Camera::render_async(&World) -> Canvas
+            for _ in range(4):
+                q1.step()
+            sync()
+            reset_stats()
+            ctx.set_timing(1)
+            dt = timed(q1.step, q1.flush, sync, n2, None)
+            s2 = stats()
+            t1 = ctx.kernel_times_ms(1024)
+            secondary["single_view"] = (dt, s2["rays_primary"] + s2["rays_shadow"], n2, float(np.mean(t1)) if len(t1) else 0.0)
+
+    # ---- outside the timed region: the frame member 0 assembled must be the frame one GPU renders, bit for bit
     exchange_check = None
-    if root and state.get("last", -1) >= 0:
-        k = state["last"]
-        slot, b = k % K, (k // K) % nbuf
-        got = (frames[b][slot] if need_copy else canvases[b])[:H]
+    if grouped and rank == 0 and args.exchange != "none":
+        state["what"] = rtc.GATHER_F64 | rtc.GATHER_U8
+        launch(1)
+        sync()
+        b = (state["batch"] - 1) & 1
+        c1 = rtc.Context(dev_index)
+        d1 = c1.upload(world)
         ref = torch.zeros((H, W, 3), dtype=torch.float64, device=dev)
         ref8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
-        dworld.render_rows(cam, 0, H, ref.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=ref8.data_ptr())
         torch.cuda.synchronize(dev)
-        want = ref8 if args.gather == "u8" else ref
-        exchange_check = "ok" if torch.equal(got.to(want.device), want) else "MISMATCH"
+        d1.render_rows(cam, 0, H, ref.data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=ref8.data_ptr())
+        c1.synchronize()
+        exchange_check = "ok" if (torch.equal(canv[b][0], ref) and torch.equal(canv8[b][0], ref8)) else "MISMATCH"
+        d1.close()
+        c1.close()
+    elif grouped and args.exchange != "none":
+        state["what"] = rtc.GATHER_F64 | rtc.GATHER_U8
+        launch(1)
+        sync()
+
+    # ---- host-canvas drop-in (PCIe-inclusive), all ranks fill ONE shared host canvas side by side
+    dropin = None
+    if not args.no_dropin:
+        dropin = measure_dropin(rtc, np, torch, dev_index, world, cam, grouped, group if grouped else None,
+                                gworld if grouped else None, rank, N, barrier)
+
     agg = torch.tensor([elapsed, float(st["rays_primary"]), float(st["rays_shadow"]), float(st["rays_reflect"] + st["rays_refract"]),
-                        kernel_ms], dtype=torch.float64, device=torch.device("cpu") if gloo else dev)
-    if dist_on:
-        tmax = agg[[0, 4]].clone()
+                        kernel_ms_per_frame] + [x for v in secondary.values() for x in v[:2]], dtype=torch.float64, device=dev)
+    if grouped:
+        tmax = agg.clone()
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        elapsed, kernel_ms_max = float(tmax[0]), float(tmax[1])
+        elapsed, kpf_max = float(tmax[0]), float(tmax[4])
     else:
-        kernel_ms_max = kernel_ms
-    rays_ps = float(agg[1] + agg[2])          # primary + shadow, whole job, over the timed steps
-    rays_other = float(agg[3])
+        tmax, kpf_max = agg, kernel_ms_per_frame
+    rays_ps, rays_other = float(agg[1] + agg[2]), float(agg[3])
 
     if rank == 0:
         steps = max(1, args.steps)
         value = rays_ps / elapsed / 1e6
-        rows = rows_mine
-        frames_per_launch = args.steps / max(1, state["launches"] - launches_before)   # V, or a little less if steps % V != 0
-        abytes = algorithmic_bytes(W, rows * frames_per_launch, world)   # per LAUNCH: that many frames' worth of this rank's rows, the scene once
-        rays_rank = (st["rays_primary"] + st["rays_shadow"] + st["rays_reflect"] + st["rays_refract"]) / steps
-        hits_rank = st["rays_shadow"] / steps  # one shadow ray per shaded hit (shape.rs:688)
-        aflops = algorithmic_flops(world, rays_rank, hits_rank) * frames_per_launch     # per launch, like kernel_ms
-        workload = (f"{W}x{H}, {args.spheres} spheres" + ("" if args.no_plane else " + checker floor plane") +
-                    ", 1 point light, render_async, SplitMix64 seed 13" + (", reflective depth 5" if args.reflective else ""))
-        traffic = measured_traffic(workload, V) if world_size == 1 else None
+        abytes = algorithmic_bytes(W, rows_mine * kernel_frames, world)   # one launch: kernel_frames frames of this member's rows, the scene once
+        prof = committed_profile(wkey) if N == 1 else None
+        kernel_s = kernel_ms * 1e-3
+        roof = {"bound": "hbm", "kernel": "k_trace", "achieved": round(abytes / kernel_s / 1e9, 3) if kernel_s else None, "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(abytes / kernel_s / 1e9 / HBM_PEAK_GBS, 6) if kernel_s else None,
+                "traffic": int(prof[0]["traffic_bytes"] * kernel_frames) if prof else None, "traffic_source": prof[1] if prof else None,
+                "algorithmic_bytes_per_launch": int(abytes), "frames_per_launch": kernel_frames,
+                "kernel_ms_avg": round(kernel_ms, 5), "kernel_ms_per_frame": round(kernel_ms_per_frame, 6),
+                "kernel_launches_timed": int(len(times)), "kernel_launches_of_full_size": len(full), "kernel_timed_every": args.time_every,
+                "note": "algorithmic bytes of one launch (its f64 canvases written once + the scene read once) / that launch's duration by "
+                        "HIP events on the launch stream; launches of fewer frames (steps % frames_per_launch) are left out of the average. "
+                        "The kernel is f64-VALU/latency bound, not HBM bound: see valu_issue and DESIGN.md"}
         out = {
-            "metric": baseline_metric(),
-            "value": round(value, 3),
-            "unit": "Mrays/s",
-            "n_gpus": world_size,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": round(elapsed / steps * 1e3, 4),
-            "higher_is_better": True,
-            "scaling": "strong",
-            "vs_baseline": None,
-            "dtype": "f64",
-            "data": "synthetic",
+            "metric": baseline_metric(), "value": round(value, 3), "unit": "Mrays/s", "n_gpus": N, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / steps * 1e3, 4), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
             "config": {
-                "workload": workload,
-                "objects": len(world), "rows_per_gpu": rows, "frames_per_launch": V, "parallelism": (f"{'8-row bands dealt round-robin' if banded else 'contiguous row tiles'} x{world_size} + {'gloo (rehearsal)' if gloo else 'RCCL'} gather of the "
-                                                                          f"{'8-bit frame (Color::scale)' if args.gather == 'u8' else 'f64 canvas'} to rank 0"
-                                                                          + (f", one gather per {K} frames" if K > 1 else "")
-                                                                          + (f", {in_flight} frames in flight (HIP streams measured to run side by side)" if in_flight > 1 else "")
-                                                                          + ("" if args.no_overlap else ", gather of batch j overlapped with the renders of batch j+1")) if dist_on else ("single GPU" + (f", {in_flight} frames in flight (HIP streams measured to run side by side)" if in_flight > 1 else "")),
-                "exchange_bytes_per_frame": (W * H * (3 if args.gather == "u8" else 24) * (world_size - 1) // world_size) if dist_on else 0,
+                "workload": wdesc, "workload_key": wkey, "objects": len(world), "rows_per_gpu": rows_mine, "frames_per_launch": V,
+                "parallelism": ("single GPU" if not grouped else
+                                f"8-row bands dealt round-robin over {N} GPUs behind the C-ABI (rtc_group), one RCCL gather (ncclGather) per batch of "
+                                f"{V} frames of the {'f64 Canvas' if args.exchange == 'f64' else '8-bit frame' if args.exchange == 'u8' else 'nothing (tiles stay put)'}"
+                                " to member 0 + un-deal kernel; exchange of batch j overlapped with the render of batch j+1"),
+                "exchange": args.exchange if grouped else None,
+                "exchange_bytes_per_frame": (W * H * {"f64": 24, "u8": 3, "none": 0}[args.exchange] * (N - 1) // N) if grouped else 0,
                 "rays_per_frame_primary_shadow": int(round(rays_ps / steps)), "rays_per_frame_other": int(round(rays_other / steps)),
             },
-            "roofline": {
-                "bound": "hbm", "kernel": "k_trace", "achieved": round(abytes / (kernel_ms * 1e-3) / 1e9, 3), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(abytes / (kernel_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
-                "traffic": int(traffic[0]) if traffic else None, "traffic_source": traffic[1] if traffic else None,
-                "algorithmic_bytes_per_launch": int(abytes), "kernel_ms_avg": round(kernel_ms, 5), "kernel_ms_last_launch": round(last_ms, 5),
-                "kernel_launches_timed": int(len(times)), "kernel_timed_every": time_every,
-                "note": "one launch writes the f64 canvas tile once and reads the ~50 KB scene; the kernel is f64-VALU/latency bound, see DESIGN.md",
-            },
-            "valu_roofline": {
-                "bound": "fp64_valu_no_fma", "achieved": round(aflops / (kernel_ms * 1e-3) / 1e12, 4), "peak": FP64_PEAK_TINSTR,
-                "unit": "T f64-instr/s", "frac": round(aflops / (kernel_ms * 1e-3) / 1e12 / FP64_PEAK_TINSTR, 5),
-                "algorithmic_flops_per_launch": int(aflops),
-            },
+            "roofline": roof,
             "device": ctx.device_info(),
         }
-        if world_size > 1:
-            out["config"]["kernel_ms_max_over_ranks"] = round(kernel_ms_max, 5)
+        if prof and kernel_ms_per_frame:
+            insts = prof[0]["insts_valu"]
+            out["valu_issue"] = {"bound": "valu_issue_slots", "insts_valu_per_frame": int(insts), "cycles_per_inst": 4,
+                                 "frac": round(insts * 4 / (SIMDS * kernel_ms_per_frame * 1e-3 * CLOCK_HZ), 4), "source": prof[1],
+                                 "note": "SQ_INSTS_VALU (wave-instructions, PMC pass of the committed profile) x 4 issue cycles / (1024 SIMDs x kernel "
+                                         "time per frame x 2.4 GHz); a lower bound of the VALU pipes' occupancy (f64 divides and square roots take longer)"}
+        if N > 1:
+            out["config"]["kernel_ms_per_frame_max_over_ranks"] = round(kpf_max, 6)
         if exchange_check is not None:
             out["config"]["gathered_frame_vs_single_gpu_render"] = exchange_check
-        if pipelined is not None:
-            out["pipelined"] = pipelined
-        if world_size == 1 and not args.no_cpu_baseline:
+        k = 5
+        for name, v in secondary.items():
+            dt, rays = float(tmax[k]), float(agg[k + 1])
+            k += 2
+            rec = {"value": round(rays / dt / 1e6, 3), "unit": "Mrays/s", "ms_per_step": round(dt / v[2] * 1e3, 4), "steps": v[2]}
+            if name == "single_view":
+                rec.update(frames_per_launch=1, kernel_ms_per_frame=round(v[3], 6),
+                           note="one camera per launch, the shape of Camera::render_async(&World) -> Canvas; canvas left in HBM")
+            else:
+                rec["note"] = {"exchange_u8": "same run, member 0 collects the 8-bit frame (Color::scale, 3 B/pixel) instead of the f64 Canvas",
+                               "exchange_f64": "same run, member 0 collects the f64 Canvas (24 B/pixel)",
+                               "exchange_none": "same run, no exchange: every GPU keeps its tile (the render side alone)"}[name]
+            out[name] = rec
+        if dropin is not None:
+            out["dropin"] = dropin
+        if N == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(world, cam, args.cpu_seconds)
         print(json.dumps(out), flush=True)
 
-    for d_, c in everything:
-        d_.close()
-        c.close()
-    if dist_on:
+    if grouped:
+        gworld.close()
+        group.close()
         dist.destroy_process_group()
+    else:
+        dworld.close()
+        ctx.close()
+
+
+def measure_dropin(rtc, np, torch, dev_index, world, cam, grouped, group, gworld, rank, N, barrier):
+    """What a caller of Camera::render_async(&World) -> Canvas pays when the Canvas lives in host memory
+    (canvas.rs:16-22): context + world set-up, then one synchronous call per frame."""
+    W, H = cam.hsize, cam.vsize
+    nbytes = W * H * 24
+    frames = 3 if nbytes < 1 << 28 else 1
+    out = {"canvas_bytes": nbytes, "frames_timed": frames}
+
+    def per_frame(fn):
+        fn()
+        if barrier:
+            barrier()
+        t = time.perf_counter()
+        for _ in range(frames):
+            fn()
+        if barrier:
+            barrier()
+        return round((time.perf_counter() - t) / frames * 1e3, 4)
+
+    if not grouped:
+        ts = []
+        for _ in range(5):
+            t = time.perf_counter()
+            c = rtc.Context(dev_index)
+            ts.append(time.perf_counter() - t)
+            c.close()
+        out["context_create_ms"] = round(sorted(ts)[2] * 1e3, 4)
+        c = rtc.Context(dev_index)
+        ts = []
+        for _ in range(3):
+            t = time.perf_counter()
+            d = c.upload(world)
+            ts.append(time.perf_counter() - t)
+            d.close()
+        out["world_upload_ms"] = round(sorted(ts)[1] * 1e3, 4)
+        d = c.upload(world)
+        pageable = np.empty((H, W, 3), dtype=np.float64)
+        pageable[...] = 0.0
+        out["rtc_render_pageable_ms"] = per_frame(lambda: d.render(cam, out=pageable))
+        rtc.host_register(pageable)
+        out["rtc_render_registered_ms"] = per_frame(lambda: d.render(cam, out=pageable))
+        rtc.host_unregister(pageable)
+        pinned = rtc.host_canvas(H, W)
+        out["rtc_render_pinned_ms"] = per_frame(lambda: d.render(cam, out=pinned))
+        out["note"] = ("ms per 1-camera frame INCLUDING the copy of the f64 canvas to host memory over PCIe (never `value`): pageable = a plain "
+                       "allocation, registered = the same allocation after rtc_host_register, pinned = rtc_host_alloc")
+        d.close()
+        c.close()
+    else:
+        # every rank maps ONE shared-memory canvas and DMAs its own bands into it over its own PCIe link
+        path = f"/dev/shm/rtc_bench_canvas_{os.environ.get('MASTER_PORT', '0')}"
+        if rank == 0:
+            with open(path, "wb") as f:
+                f.truncate(nbytes)
+        barrier()
+        shared = np.memmap(path, dtype=np.float64, mode="r+", shape=(H, W, 3))
+        rtc.host_register(shared)
+        out["rtc_group_render_host_ms"] = per_frame(lambda: gworld.render_host(cam, shared))
+        ok = True
+        if rank == 0:
+            c = rtc.Context(dev_index)
+            ok = bool(np.array_equal(np.asarray(shared), c.upload(world).render(cam)))
+            c.close()
+        out["shared_canvas_vs_single_gpu_render"] = "ok" if ok else "MISMATCH"
+        out["note"] = (f"ms per frame for Camera::render_async into ONE host canvas (shared memory, page-locked in every process): each of the {N} "
+                       "GPUs DMAs its bands straight to their rows over its own PCIe link (rtc_group_render_host); no gather")
+        rtc.host_unregister(shared)
+        del shared
+        barrier()
+        if rank == 0:
+            os.unlink(path)
+    return out
 
 
 def cpu_baseline(world, cam, budget_s):

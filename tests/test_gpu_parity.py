@@ -401,26 +401,49 @@ def test_interleaved_bands_compose_the_frame(rtc, gpu, scenes, H):
     dw.close()
 
 
-@pytest.mark.parametrize("extra", [["--frames-per-exchange", "4"], ["--frames-per-exchange", "1", "--tiling", "rows"],
-                                   ["--gather", "f64", "--frames-per-exchange", "3"]])
-def test_bench_exchange_path_with_one_rank(extra):
-    """bench.py's distributed path (process group, batched RCCL gather, un-deal copy) with a single
-    rank: the frame rank 0 assembles must equal a plain render; the line carries the contract keys."""
+@pytest.mark.parametrize("extra", [["--exchange", "f64"], ["--exchange", "u8", "--views-per-launch", "3"], ["--exchange", "none"]])
+def test_bench_group_path_with_one_rank(extra):
+    """bench.py's multi-GPU path (rtc_group in rank mode: RCCL communicator from a broadcast id, ncclGather per
+    batch, un-deal kernel, shared host canvas) with a single rank: the frame member 0 assembles must equal a plain
+    render; the line carries the contract keys and the secondary exchange records."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29547")
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "11", "--warmup", "2",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-group", "--steps", "11", "--warmup", "2",
                         "--no-cpu-baseline", "--width", "320", "--height", "203", "--spheres", "20"] + extra,
                        capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["config"]["gathered_frame_vs_single_gpu_render"] == "ok"
+    if "none" not in extra:
+        assert line["config"]["gathered_frame_vs_single_gpu_render"] == "ok"
+    assert line["dropin"]["shared_canvas_vs_single_gpu_render"] == "ok"
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline"):
         assert key in line
-    assert line["steps"] == 11 and line["n_gpus"] == 1 and 2 <= line["roofline"]["kernel_launches_timed"] <= 11
+    assert line["steps"] == 11 and line["n_gpus"] == 1 and 1 <= line["roofline"]["kernel_launches_timed"] <= 11
+    assert sum(k.startswith("exchange_") for k in line) == 2 and line["roofline"]["frac"] < 1
+
+
+def test_bench_single_gpu_line_is_robust_to_ragged_steps():
+    """--steps not a multiple of the frames per launch (the driver runs --steps 20 with 8 frames per launch): the roofline
+    averages full-size launches only, per-frame kernel time is reported, single_view and dropin records are present."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline",
+                        "--width", "640", "--height", "360"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    rf = line["roofline"]
+    assert rf["frames_per_launch"] == 8 and rf["kernel_launches_timed"] == 3 and rf["kernel_launches_of_full_size"] == 2
+    assert abs(rf["kernel_ms_avg"] / 8 - rf["kernel_ms_per_frame"]) < 0.5 * rf["kernel_ms_per_frame"] and 0 < rf["frac"] < 1
+    assert line["single_view"]["frames_per_launch"] == 1 and line["single_view"]["value"] > 0
+    d = line["dropin"]
+    assert d["context_create_ms"] < 5 and d["rtc_render_pinned_ms"] <= d["rtc_render_pageable_ms"] * 1.5
+    assert "valu_roofline" not in line
 
 
 @pytest.mark.parametrize("reflective", [False, True])
