@@ -410,7 +410,8 @@ rtc_status  rtc_group_stats_reset(rtc_group *g);
 
 /* World::color_at(ray, remaining) (shape.rs:702-710) for `n` arbitrary host rays
  * (n x {origin xyz, direction xyz}); writes n x rgb and, if hits != NULL, the hit record
- * of each ray's first intersection. Synchronous. */
+ * of each ray's first intersection. remaining <= RTC_MAX_REFLECTIONS (what Camera::render_pixel passes,
+ * camera.rs:98; the kernels' frame stack holds that many suspended shade_hit calls). Synchronous. */
 rtc_status  rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays, uint32_t n,
                          uint32_t remaining, uint32_t flags, double *rgb, rtc_hit *hits);
 

@@ -497,7 +497,7 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     P.flags = flags;
     if (P.samples != 1u) { // the 4 sub-samples of every pixel wait in LDS for the resample test (camera.rs:108)
         P.aa_lds_off = (uint32_t)lds_bytes;
-        lds_bytes += (size_t)RTC_BLOCK_OF(w->any_refl || w->any_refr) * 12u * sizeof(double);
+        lds_bytes += (size_t)RTC_BLOCK_OF(w->any_refl || w->any_refr) * 15u * sizeof(double); // + the running sums
         // Camera::resample traces `antialiasing_samples` more rays (camera.rs:87); u8 in the reference
         P.resample_n = (flags & RTC_FLAG_AA_RESAMPLE) ? (cam->samples & 0xffu) : 0u;
     }
@@ -706,7 +706,7 @@ rtc_status rtc_host_unregister(void *p) {
 rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays, uint32_t n, uint32_t remaining,
                         uint32_t flags, double *rgb, rtc_hit *hits) {
     if (!ctx || !w || !rays || !rgb || w->ctx != ctx) return RTC_ERR_ARG;
-    if (remaining > 7) return RTC_ERR_ARG; // frame stack depth of the kernel (reference uses <= 5)
+    if (remaining > RTC_MAX_REFLECTIONS) return RTC_ERR_ARG; // frame stack depth of the kernel = Camera::MAX_REFLECTIONS (camera.rs:31)
     if (n == 0) return RTC_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     double *d_rays = nullptr, *d_rgb = nullptr;

@@ -30,7 +30,18 @@
 #include "rtc.h"
 #include "rtc_device.h"
 
-#define RTC_MAX_STACK 8
+// Depth of the reflection / refraction frame stack. A frame is pushed only by a color_at call whose
+// `remaining` is not 0, and each level passes remaining - 1 on (shape.rs:730,735,752,765): a chain started with
+// remaining = 5 (Camera::MAX_REFLECTIONS, camera.rs:31) suspends at most 5 shade_hit calls.
+#define RTC_MAX_STACK 5
+// Reflection-only Worlds keep their 32-byte frames (surface, kr) in LDS instead of scratch memory: 5 levels x
+// 4 doubles x 64 lanes = 10 KB per wave, SoA ([level][component][lane]: lane-consecutive 8-byte accesses, no bank
+// conflicts). The scratch stack was HBM traffic: C4 wrote 941 MB and fetched 236 MB per frame against 453 MB
+// algorithmic (profiles/r02_a_c4_pmc.json). The output tile is staged in the same LDS (the stack is dead by then),
+// so a one-wave workgroup still fits 16 times in a CU's 160 KB. 0 = the scratch stack (A/B).
+#ifndef RTC_LDS_STACK
+#define RTC_LDS_STACK 1
+#endif
 // Tile output: true = each wave stores its own 8x8 part as soon as it is done, false = workgroup
 // barrier + cooperative store of the workgroup's whole tile (full 128-byte lines). Measured: the barrier
 // form wins for the flat kernel (0.0738 vs 0.0784 ms, 192-byte row pieces straddle lines), the
@@ -786,8 +797,8 @@ DEVI ParamPtr param_view() {
 template <bool REFR> struct FrameT;
 template <> struct FrameT<true> {
     V3 surface;
-    V3 reflected;
-    V3 ro, rd;      // pending refraction ray
+    V3 a;           // state 0: origin of the pending refraction ray; state 1: the reflected colour (the ray has left)
+    V3 rd;          // state 0: direction of the pending refraction ray
     double kr, tr, R;
     uint8_t rem;    // `remaining` of the color_at call that owns the frame
     uint8_t state;  // 0 waiting for the reflected child, 1 waiting for the refracted child
@@ -836,8 +847,14 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
         const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound, const DevIdEntry *__restrict__ t_idtab) {
     constexpr uint32_t BLOCK = RTC_BLOCK_OF(REFL), TILE_W = RTC_TILE_W_OF(REFL);
     extern __shared__ double lds_raw[];
-    __shared__ __attribute__((aligned(16))) double stage_f64[PROBE ? 1 : 8 * TILE_W * 3];      // the tile, canvas layout
-    __shared__ __attribute__((aligned(16))) unsigned char stage_u8[PROBE ? 16 : 8 * TILE_W * 3];
+    constexpr bool LDS_STACK = RTC_LDS_STACK && REFL && !REFR; // 32-byte frames in LDS (one wave per workgroup)
+    static_assert(!LDS_STACK || BLOCK == 64, "the LDS frame stack and the tile staged over it assume one wave per workgroup");
+    __shared__ __attribute__((aligned(16))) double stack_lds[LDS_STACK ? RTC_MAX_STACK * 4 * BLOCK : 2];
+    __shared__ __attribute__((aligned(16))) double stage_own[(PROBE || LDS_STACK) ? 2 : 8 * TILE_W * 3];     // the tile, canvas layout
+    __shared__ __attribute__((aligned(16))) unsigned char stage_own8[(PROBE || LDS_STACK) ? 16 : 8 * TILE_W * 3];
+    // with the LDS stack the tile is staged over it (every lane's stack is empty when its sample is done)
+    double *const stage_f64 = LDS_STACK ? stack_lds : stage_own;
+    unsigned char *const stage_u8 = LDS_STACK ? reinterpret_cast<unsigned char *>(stack_lds + 8 * TILE_W * 3) : stage_own8;
     const auto &P = KP(P_arg); // set-up view: grid, sizes, mode
     const LdsView L = lds_view(lds_raw, P.tile_cap);
     Tables T;
@@ -899,11 +916,13 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     uint32_t nsamples = aa ? 4u : 1u;   // grows to 4 + resample_n after sample 3 when some lane resamples
     bool lane_resample = false;         // this lane's pixel tripped the test AND the resample is enabled
     uint32_t c_resample = 0;            // wave-uniform: pixels that tripped the test
-    double *aa_store = reinterpret_cast<double *>(reinterpret_cast<char *>(lds_raw) + P.aa_lds_off) + threadIdx.x * 12u;
+    // per thread: the four sub-samples (12 doubles) and Color::average_over's running sums (3 doubles)
+    double *aa_store = reinterpret_cast<double *>(reinterpret_cast<char *>(lds_raw) + P.aa_lds_off) + threadIdx.x * 15u;
     V3 result = mk(0., 0., 0.);
 
     typedef FrameT<REFR> Frame;
-    Frame stack[REFL ? RTC_MAX_STACK : 1];
+    Frame stack[(REFL && !LDS_STACK) ? RTC_MAX_STACK : 1];
+    double *const lstk = stack_lds + threadIdx.x; // LDS stack: level l, component c at lstk[(l*4 + c) * BLOCK]
 
     for (uint32_t s = 0; s < nsamples; ++s) {
         V3 ro, rd;
@@ -1197,21 +1216,25 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     if constexpr (REFR) {
                         Frame &F = stack[sp];
                         F.surface = surface;
-                        F.reflected = mk(0., 0., 0.);
-                        F.ro = fr_o; F.rd = fr_d;
+                        F.a = fr_o; F.rd = fr_d;
                         F.kr = m_kr; F.tr = m_tr; F.R = R;
                         F.rem = (uint8_t)rem;
                         F.state = want_refl ? 0 : 1;
                         F.schlick = schlick ? 1 : 0;
-                        F.has_refr = want_refr ? 1 : 0;
+                        F.has_refr = want_refr ? (want_refl ? 1 : 2) : 0; // 2: refraction only, no reflected colour will arrive
                         ++sp;
                         if (want_refl) { ro = over; rd = reflectv; l_refl = true; } // Ray::new(over_point, reflectv) shape.rs:734
                         else { ro = fr_o; rd = fr_d; l_refr = true; }               // Ray::new(under_point, direction) shape.rs:764
                         rem = rem - 1;
                     } else if constexpr (REFL) { // reflection only: want_refl holds here
-                        Frame &F = stack[sp];
-                        F.surface = surface;
-                        F.kr = m_kr;
+                        if constexpr (LDS_STACK) {
+                            double *f = lstk + (uint32_t)sp * 4u * BLOCK;
+                            f[0] = surface.x; f[BLOCK] = surface.y; f[2 * BLOCK] = surface.z; f[3 * BLOCK] = m_kr;
+                        } else {
+                            Frame &F = stack[sp];
+                            F.surface = surface;
+                            F.kr = m_kr;
+                        }
                         ++sp;
                         ro = over; rd = reflectv; l_refl = true;                     // shape.rs:734
                         rem = rem - 1;
@@ -1225,8 +1248,13 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 bool relaunched = false;
                 if constexpr (REFL && !REFR) {
                     while (sp > 0) { // surface + reflected + refracted(BLACK), innermost call first shape.rs:692-699
-                        const Frame &F = stack[sp - 1];
-                        val = combine(F.surface, vmul(val, F.kr), mk(0., 0., 0.), false, 0.);
+                        if constexpr (LDS_STACK) {
+                            const double *f = lstk + (uint32_t)(sp - 1) * 4u * BLOCK;
+                            val = combine(mk(f[0], f[BLOCK], f[2 * BLOCK]), vmul(val, f[3 * BLOCK]), mk(0., 0., 0.), false, 0.);
+                        } else {
+                            const Frame &F = stack[sp - 1];
+                            val = combine(F.surface, vmul(val, F.kr), mk(0., 0., 0.), false, 0.);
+                        }
                         --sp;
                     }
                 }
@@ -1234,20 +1262,24 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     while (sp > 0) {
                         Frame &F = stack[sp - 1];
                         if (F.state == 0) {
-                            F.reflected = vmul(val, F.kr); // c.mul_f64(reflectiveness) shape.rs:736
+                            const V3 reflected = vmul(val, F.kr); // c.mul_f64(reflectiveness) shape.rs:736
                             if (F.has_refr) { // now refracted_color's recursion shape.rs:764-765
                                 F.state = 1;
-                                ro = F.ro; rd = F.rd;
+                                ro = F.a; rd = F.rd;
+                                F.a = reflected;     // the pending ray has left the frame: its slot keeps the reflected colour
                                 rem = (int)F.rem - 1;
                                 relaunched = true;
                                 l_refr = true;
                                 break;
                             }
-                            val = combine(F.surface, F.reflected, mk(0., 0., 0.), F.schlick != 0, F.R);
+                            val = combine(F.surface, reflected, mk(0., 0., 0.), F.schlick != 0, F.R);
                             --sp;
                         } else {
+                            // a frame that never launched a reflection ray (state 1 from the start) holds the refraction
+                            // ray's origin in `a`; its reflected colour is BLACK (reflected_color shape.rs:730-732)
+                            const V3 reflected = F.has_refr == 2 ? mk(0., 0., 0.) : F.a;
                             const V3 refracted = vmul(val, F.tr); // shape.rs:765
-                            val = combine(F.surface, F.reflected, refracted, F.schlick != 0, F.R);
+                            val = combine(F.surface, reflected, refracted, F.schlick != 0, F.R);
                             --sp;
                         }
                     }
@@ -1280,16 +1312,16 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             // bytes of the f64 canvas (three full 128-byte lines) and 48 contiguous bytes of the 8-bit frame,
             // stored 16 bytes per lane. Direct per-pixel stores (3 x 8 B at a 24 B stride, 3 single
             // bytes) cost 1.6x the algorithmic bytes in HBM write traffic (rocprofv3 WRITE_SIZE).
-            // Between AA samples the LDS slot also holds Color::average_over's running sums
-            // (color.rs:128-139: reds = ((0 + c0) + c1) + ...).
+            // Between AA samples Color::average_over's running sums (color.rs:128-139: reds = ((0 + c0) + c1) + ...)
+            // wait in the thread's part of the dynamic LDS block (the tile may be staged over the frame stack).
             const uint32_t tx = wave * 8u + (lane & 7u), ty = lane >> 3; // position inside the tile
             double *slot = stage_f64 + (ty * TILE_W + tx) * 3u;
             if (!traced) result = mk(0., 0., 0.); // Canvas::new BLACK canvas.rs:37-41
             if (aa) {
-                // the slot holds Color::average_over's running sums (reds = ((0 + c0) + c1) + ..., color.rs:128-139)
+                // aa_store[12..14] hold Color::average_over's running sums (reds = ((0 + c0) + c1) + ..., color.rs:128-139)
                 // while a lane still collects samples, and the pixel's final colour afterwards
                 const bool collecting = s < 4u || lane_resample;
-                V3 acc = (s == 0u) ? mk(0., 0., 0.) : mk(slot[0], slot[1], slot[2]);
+                V3 acc = (s == 0u) ? mk(0., 0., 0.) : mk(aa_store[12], aa_store[13], aa_store[14]);
                 if (collecting) acc = vadd(acc, result);
                 if (s < 4u) { aa_store[s * 3u] = result.x; aa_store[s * 3u + 1u] = result.y; aa_store[s * 3u + 2u] = result.z; }
                 if (s == 3u) {
@@ -1316,11 +1348,12 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     acc = mk(acc.x / l, acc.y / l, acc.z / l);
                 }
                 result = acc;
+                aa_store[12] = acc.x; aa_store[13] = acc.y; aa_store[14] = acc.z;
             }
-            slot[0] = result.x;
-            slot[1] = result.y;
-            slot[2] = result.z;
             if (s + 1u == nsamples) {
+                slot[0] = result.x;
+                slot[1] = result.y;
+                slot[2] = result.z;
                 const auto &Po = KP(P_arg); // output view
                 const bool want8 = Po.out8 != nullptr;
                 if (want8) {
