@@ -52,6 +52,15 @@ struct DevBound {
     double k;             // 0.75e-14 * ||A||_F^2 (A = 3x3 of the stored inverse): rounding inflation
     double cn;            // |centre|: see the note on rounding below
 };
+// The same bound for the WAVE-LEVEL cull (bundle_touches), in f32: the bundle itself is built in f32, and the test runs
+// once per (lane, object) 64 objects at a time — it is most of a large world's instruction count. Conservative by
+// construction: r, k, cn are rounded UP, and `ec` >= the error of rounding the centre to f32 (2e-7 * |c|_1), which the
+// test adds to the radius together with the same term for the apex. r = +inf: never culled (as DevBound).
+struct DevBound32 {
+    float cx, cy, cz, r;
+    float k, cn, ec, _pad;
+};
+
 // Rounding note. The cull must never drop an object for which the REFERENCE ARITHMETIC reports an
 // intersection — including intersections that exist only because of rounding. The sphere test
 // evaluates disc = b*b - 4*a*c with b^2 and 4ac of size ~4a|o'|^2 (o' = object-space ray origin);
@@ -65,7 +74,7 @@ struct DevBound {
 // is r * (1 + k * D * (cn + D)) with k = 0.75e-14 * ||A||_F^2 (any upper bound of D may be used).
 // For ordinary scenes the factor is 1 + 1e-9.
 
-enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PIXELS = 4, CNT_RESAMPLE = 5, CNT_STAMP0 = 8, CNT_DIAG0 = 16, CNT_N = 24 };
+enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PIXELS = 4, CNT_RESAMPLE = 5, CNT_STAMP0 = 8, CNT_DIAG0 = 16, CNT_N = 32 };
 // Ray counters are kept in CNT_SLOTS replicas (one 64-byte line each); a wave adds to the replica
 // picked by its workgroup id, so no single word sees more than 1/CNT_SLOTS of the atomics. The host
 // sums the replicas (rtc_stats_read).
@@ -107,6 +116,9 @@ struct RenderParams {
     const uint32_t *orig_s;    // [n] sorted position -> insertion index (World.shapes order)
     const DevBound *gbound;    // [ngroups] sphere around each group of 64 sorted objects
     const DevIdEntry *idtab;   // [n] shapes in stable order of world_id (compute_refractive's container key)
+    const DevBound32 *bound32;   // [n]       f32 twins of bound / bound_s / gbound for the wave-level cull
+    const DevBound32 *bound32_s; // [n]
+    const DevBound32 *gbound32;  // [ngroups]
     uint32_t ngroups;
     uint32_t n;
     uint32_t tile_cap; // objects per LDS tile (LDS variants)

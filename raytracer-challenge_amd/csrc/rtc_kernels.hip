@@ -62,6 +62,22 @@
 #ifndef RTC_PRIMARY_LANE_FILTER
 #define RTC_PRIMARY_LANE_FILTER(SRC) false
 #endif
+// Two-level cull, group level. 1 (default): one ROUND tests up to RTC_GROUP_SLOTS x 64 group spheres against the
+// bundle at once (their loads overlap) and, for ordered walks (primary rays of large worlds), queues the
+// survivors' keys in a wave-private LDS array: groups are then expanded nearest-first across the WHOLE round and
+// the walk stops at the first key no lane can use. 0: the round-1 form, 64 groups per step, each step walked
+// (and ordered) on its own before the next step's groups are even tested.
+#ifndef RTC_GROUP_QUEUE
+#define RTC_GROUP_QUEUE 1
+#endif
+// Wave-level cull arithmetic: 1 (default) = f32 test on the f32 bound tables (bundle_touches32: the bundle is an f32
+// object anyway; ~35 two-cycle instructions against ~50 four-cycle f64 ones per 64 objects), 0 = the round-1 f64 test.
+#ifndef RTC_CULL_F32
+#define RTC_CULL_F32 1
+#endif
+#ifndef RTC_GROUP_SLOTS
+#define RTC_GROUP_SLOTS 4
+#endif
 #ifndef RTC_TILE_ORDER
 // Workgroup id -> tile. The hardware deals consecutive workgroup ids round-robin over the 8 XCDs.
 // 1 (default): tile = workgroup id, so every XCD gets every 8th tile of the image — an even share
@@ -363,6 +379,9 @@ struct Bundle {
                          // primary rays, rho for secondary rays, tmax for shadow segments, whose
                          // exact rays start at the far end)
     bool off;            // bundle could not be bounded: every object is a candidate
+    // the same bundle for the f32 test (bundle_touches32); everything but the apex is an f32 value to begin with
+    float fpx, fpy, fpz, fax, fay, faz, fcos, fsin, frho, ftmax, fspread;
+    float fep;           // >= the error of rounding the apex to f32 (2e-7 * |apex|_1)
 };
 
 // A wave-uniform double that the compiler would otherwise keep in two VGPRs: move it to SGPRs.
@@ -371,6 +390,8 @@ DEVI double uniform_f64(double x) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
+
+DEVI float uniform_f32(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
 
 DEVI bool finite3(V3 v) { return fabs(v.x) < __builtin_inf() && fabs(v.y) < __builtin_inf() && fabs(v.z) < __builtin_inf(); }
 
@@ -457,6 +478,15 @@ DEVI Bundle make_bundle(bool active, V3 apex, V3 o, V3 d, double reach) {
     B.tmax = uniform_f64((double)tmax);
     B.spread = REACH ? B.tmax : B.rho;
     if (!(B.spread < 1e300)) off = true; // shadow segment of unbounded length: do not cull
+    B.fpx = uniform_f32((float)apex.x); B.fpy = uniform_f32((float)apex.y); B.fpz = uniform_f32((float)apex.z);
+    B.fax = ax; B.fay = ay; B.faz = az;
+    B.fcos = uniform_f32(cosT); B.fsin = uniform_f32(sinT);
+    B.frho = uniform_f32(rho);
+    B.ftmax = uniform_f32(tmax);
+    B.fspread = REACH ? B.ftmax : B.frho;
+    const float pl1 = fabsf(B.fpx) + fabsf(B.fpy) + fabsf(B.fpz);
+    B.fep = pl1 * 2e-7f + 1e-30f;
+    if (!(pl1 < 1e30f)) off = true;
     B.off = off;
     return B;
 }
@@ -501,6 +531,41 @@ template <bool KEYED = false> DEVI bool bundle_touches(const Bundle &B, const De
     if (rhs < 0.) return false;
     const double perp2 = d2 - wa * wa * 1.00001;
     return !(perp2 * (B.cosT * B.cosT) > rhs * rhs);   // NaN-safe: keep the object unless provably far
+}
+
+// The same test in f32 on the f32 twin of the bound (DevBound32). Sources of error and where they go:
+//  * centre and apex rounded to f32: |w_f32 - w_true| <= b.ec + B.fep + 2^-24 |w| — added to the radius (Re);
+//  * f32 rounding of d2, wa (relative <= 3 * 2^-24 of |w|^2, |w|): Re carries 4e-6 * |w|_1, the cone inequality
+//    3e-6 * d2 on the "keep" side; axis / (cos, sin) unit only to ~2e-6: the 2e-5 factors;
+//  * r, k, cn are rounded up when the table is built (rtc_api.cpp, bound32_of).
+// Overflow and NaN fall through to "keep". Every inequality errs towards keeping the object; the exact f64 test
+// decides for what is kept, so results equal brute force bit for bit (tests/stress_parity.py).
+template <bool KEYED = false> DEVI bool bundle_touches32(const Bundle &B, const DevBound32 &b, float *key = nullptr) {
+#pragma clang fp contract(fast)
+    if constexpr (KEYED) *key = 0.f;
+    if (B.off) return true;
+    if (!(b.r < __builtin_inff())) return true;
+    const float wx = b.cx - B.fpx, wy = b.cy - B.fpy, wz = b.cz - B.fpz;
+    const float l1 = fabsf(wx) + fabsf(wy) + fabsf(wz);
+    const float epos = b.ec + B.fep;
+    const float Dub = (l1 + B.fspread) * 1.000001f + epos;            // >= distance centre -> ray origin
+    const float r_eff = b.r + b.r * (b.k * Dub * (b.cn + Dub)) * 1.00001f; // rounding inflation, see DevBound
+    const float Re = (r_eff + B.frho) * 1.00001f + 4e-6f * l1 + epos;
+    const float d2 = wx * wx + wy * wy + wz * wz;
+    if (!(d2 < 1e30f)) return true;
+    if (d2 <= Re * Re) return true;
+    if constexpr (KEYED) {
+        const float dist = __builtin_sqrtf(d2) * 0.99999f, rad = Re * 1.00001f;
+        *key = fmaxf(0.f, (dist - rad) * 0.99999f); // NaN / inf - inf -> 0: no bound
+    }
+    const float wa = wx * B.fax + wy * B.fay + wz * B.faz;
+    if (wa < -Re) return false;                            // wholly behind the apex plane
+    const float far = B.ftmax + Re;
+    if (d2 > far * far * 1.00001f) return false;           // beyond the reach of every ray (inf: never)
+    const float rhs = Re + (wa + fabsf(wa) * 2e-5f) * B.fsin;
+    if (rhs < 0.f) return false;
+    const float perp2 = d2 - wa * wa * 1.00002f;
+    return !(perp2 * (B.fcos * B.fcos) > rhs * rhs * 1.00001f + 3e-6f * d2); // NaN-safe: keep unless provably far
 }
 
 // Per-lane prefilter for INCOHERENT rays (reflection / refraction): can THIS lane's ray, for some
@@ -548,7 +613,13 @@ struct Tables {
     const uint32_t *__restrict__ orig_s;
     const DevBound *__restrict__ gbound;
     const DevIdEntry *__restrict__ idtab; // shapes in stable order of world_id (n1/n2 pass)
+    const DevBound32 *__restrict__ bound32, *__restrict__ bound32_s, *__restrict__ gbound32; // f32 twins (wave-level cull)
 };
+#if RTC_CULL_F32
+#define WAVE_CULL(KEYED, B, T64, T32, idx, key) bundle_touches32<KEYED>(B, (T32)[idx], key)
+#else
+#define WAVE_CULL(KEYED, B, T64, T32, idx, key) bundle_touches<KEYED>(B, (T64)[idx], key)
+#endif
 
 struct LdsView {
     double *m;      // [cap][12]
@@ -594,7 +665,8 @@ DEVI int take_min_key(unsigned long long &mask, float key, float &kmin) {
 
 template <int SRC, bool LANE_FILTER = false, class PP, class F, class SK = NoSkip>
 DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool lane_needs, const Bundle &B, F &&f,
-                          V3 fro = V3{0., 0., 0.}, V3 frd = V3{0., 0., 0.}, SK skip = SK{}, unsigned *nfilt = nullptr) {
+                          V3 fro = V3{0., 0., 0.}, V3 frd = V3{0., 0., 0.}, SK skip = SK{}, unsigned *nfilt = nullptr,
+                          unsigned *ngrp = nullptr, unsigned *nobj = nullptr) {
     constexpr bool ORDERED = !__is_same(SK, NoSkip);
     if constexpr (SRC == SRC_CULL) {
         // One-level cull (small worlds): 64 objects at a time, each lane tests one object's sphere
@@ -605,7 +677,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
         for (uint32_t base = 0; base < P.n; base += 64u) {
             const uint32_t j = base + lane;
             bool cand = false;
-            if (j < P.n) cand = bundle_touches(B, T.bound[j]);
+            if (j < P.n) cand = WAVE_CULL(false, B, T.bound, T.bound32, j, nullptr);
             unsigned long long mask = ballot(cand);
             while (mask) {
                 const uint32_t jj = base + (uint32_t)__builtin_ctzll(mask);
@@ -619,17 +691,89 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
             }
         }
     } else if constexpr (SRC == SRC_CULL2) {
-        // Two-level cull (large worlds) over the Morton-sorted tables. Level 1: 64 GROUPS at a time,
-        // one group sphere per lane against the wave's bundle. Level 2, per surviving group: its 64
-        // objects, one object sphere per lane. Objects are not visited in insertion order here, so
-        // the callback receives the insertion index and the tie-break compares it (closer()).
+        // Two-level cull (large worlds) over the Morton-sorted tables. Level 1: group spheres against the wave's
+        // bundle, one per lane. Level 2, per surviving group: its 64 objects, one object sphere per lane. Objects
+        // are not visited in insertion order here, so the callback receives the insertion index and the tie-break
+        // compares it (closer()).
         if (ballot(lane_needs) == 0ull) return;
         const uint32_t lane = threadIdx.x & 63u;
+        // level 2: the objects of group `gidx`; returns false when the walk is over (callback said so)
+        auto expand = [&](uint32_t gidx) -> bool {
+            DIAG_FILTER(ngrp);
+            const uint32_t base = gidx * 64u;
+            const uint32_t j = base + lane;
+            bool cand = false;
+            float okey = 0.f;
+            if (j < P.n) cand = WAVE_CULL(ORDERED, B, T.bound_s, T.bound32_s, j, &okey);
+            unsigned long long mask = ballot(cand);
+            while (mask) {
+                uint32_t jj;
+                if constexpr (ORDERED) {
+                    float kmin;
+                    jj = base + (uint32_t)take_min_key(mask, okey, kmin);
+                    if (skip(kmin)) break;
+                } else {
+                    jj = base + (uint32_t)__builtin_ctzll(mask);
+                    mask &= mask - 1ull;
+                }
+                DIAG_FILTER(nobj);
+                if constexpr (LANE_FILTER) {
+                    DIAG_FILTER(nfilt);
+                    if (ballot(lane_needs && ray_touches(fro, frd, T.bound_s[jj])) == 0ull) continue;
+                }
+                const DevIsect *rec = T.isect_s + jj;
+                if (!f((int)T.orig_s[jj], rec->m, T.kind_s[jj], (const double *)nullptr)) return false;
+            }
+            return true;
+        };
+#if RTC_GROUP_QUEUE
+        constexpr uint32_t SLOTS = RTC_GROUP_SLOTS;
+        for (uint32_t gbase = 0; gbase < P.ngroups; gbase += 64u * SLOTS) {
+            // one round: group (gbase + s*64 + lane) for s = 0..SLOTS-1, all loads in flight together
+            unsigned kb[SLOTS];               // ordered: key bits (keys are >= 0: they order like unsigned); ~0u = no candidate
+            unsigned long long gm[SLOTS];     // unordered: candidate masks
+            for (uint32_t sl = 0; sl < SLOTS; ++sl) {
+                const uint32_t g = gbase + sl * 64u + lane;
+                bool gc = false;
+                float gkey = 0.f;
+                if (gbase + sl * 64u < P.ngroups && g < P.ngroups) gc = WAVE_CULL(ORDERED, B, T.gbound, T.gbound32, g, &gkey);
+                kb[sl] = gc ? __builtin_bit_cast(unsigned, gkey) : 0xffffffffu;
+                gm[sl] = ballot(gc);
+            }
+            if constexpr (ORDERED) {
+                // the round's queue: nearest key first over ALL its slots. Each lane keeps its own minimum; the
+                // wave minimum picks the lane, that lane's slot is read back and struck out.
+                for (;;) {
+                    unsigned mine = kb[0];
+                    uint32_t msl = 0;
+                    for (uint32_t sl = 1; sl < SLOTS; ++sl)
+                        if (kb[sl] < mine) { mine = kb[sl]; msl = sl; }
+                    const unsigned minbits = ~wave_max_u32(~mine);
+                    if (minbits == 0xffffffffu) break;                                  // queue empty
+                    if (skip(__builtin_bit_cast(float, minbits))) break;                // ascending keys: the rest is out of reach too
+                    const int sel = (int)__builtin_ctzll(ballot(mine == minbits));
+                    const uint32_t ssl = (uint32_t)__builtin_amdgcn_readlane((int)msl, sel);
+                    for (uint32_t sl = 0; sl < SLOTS; ++sl)
+                        if (sl == ssl && lane == (uint32_t)sel) kb[sl] = 0xffffffffu;
+                    if (!expand(gbase + ssl * 64u + (uint32_t)sel)) return;
+                }
+            } else {
+                for (uint32_t sl = 0; sl < SLOTS; ++sl) {
+                    unsigned long long gmask = gm[sl];
+                    while (gmask) {
+                        const uint32_t gsel = (uint32_t)__builtin_ctzll(gmask);
+                        gmask &= gmask - 1ull;
+                        if (!expand(gbase + sl * 64u + gsel)) return;
+                    }
+                }
+            }
+        }
+#else
         for (uint32_t gbase = 0; gbase < P.ngroups; gbase += 64u) {
             const uint32_t g = gbase + lane;
             bool gc = false;
             float gkey = 0.f;
-            if (g < P.ngroups) gc = bundle_touches<ORDERED>(B, T.gbound[g], &gkey);
+            if (g < P.ngroups) gc = WAVE_CULL(ORDERED, B, T.gbound, T.gbound32, g, &gkey);
             unsigned long long gmask = ballot(gc);
             while (gmask) {
                 uint32_t gsel;
@@ -641,31 +785,10 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
                     gsel = (uint32_t)__builtin_ctzll(gmask);
                     gmask &= gmask - 1ull;
                 }
-                const uint32_t base = (gbase + gsel) * 64u;
-                const uint32_t j = base + lane;
-                bool cand = false;
-                float okey = 0.f;
-                if (j < P.n) cand = bundle_touches<ORDERED>(B, T.bound_s[j], &okey);
-                unsigned long long mask = ballot(cand);
-                while (mask) {
-                    uint32_t jj;
-                    if constexpr (ORDERED) {
-                        float kmin;
-                        jj = base + (uint32_t)take_min_key(mask, okey, kmin);
-                        if (skip(kmin)) break;
-                    } else {
-                        jj = base + (uint32_t)__builtin_ctzll(mask);
-                        mask &= mask - 1ull;
-                    }
-                    if constexpr (LANE_FILTER) {
-                        DIAG_FILTER(nfilt);
-                        if (ballot(lane_needs && ray_touches(fro, frd, T.bound_s[jj])) == 0ull) continue;
-                    }
-                    const DevIsect *rec = T.isect_s + jj;
-                    if (!f((int)T.orig_s[jj], rec->m, T.kind_s[jj], (const double *)nullptr)) return;
-                }
+                if (!expand(gbase + gsel)) return;
             }
         }
+#endif
     } else if constexpr (SRC == SRC_SMEM) {
         if (ballot(lane_needs) == 0ull) return;
         for (uint32_t j = 0; j < P.n; ++j) {
@@ -844,7 +967,8 @@ __global__ void __launch_bounds__(RTC_BLOCK_OF(REFL), (REFL ? RTC_WAVES_PER_SIMD
 k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const uint32_t *__restrict__ t_kind,
         const DevShade *__restrict__ t_shade, const DevPrim *__restrict__ t_prim, const DevBound *__restrict__ t_bound,
         const DevIsect *__restrict__ t_isect_s, const uint32_t *__restrict__ t_kind_s, const DevBound *__restrict__ t_bound_s,
-        const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound, const DevIdEntry *__restrict__ t_idtab) {
+        const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound, const DevIdEntry *__restrict__ t_idtab,
+        const DevBound32 *__restrict__ t_bound32, const DevBound32 *__restrict__ t_bound32_s, const DevBound32 *__restrict__ t_gbound32) {
     constexpr uint32_t BLOCK = RTC_BLOCK_OF(REFL), TILE_W = RTC_TILE_W_OF(REFL);
     extern __shared__ double lds_raw[];
     constexpr bool LDS_STACK = RTC_LDS_STACK && REFL && !REFR; // 32-byte frames in LDS (one wave per workgroup)
@@ -861,6 +985,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     T.isect = t_isect; T.kind = t_kind; T.shade = t_shade; T.prim = t_prim; T.bound = t_bound;
     T.isect_s = t_isect_s; T.kind_s = t_kind_s; T.bound_s = t_bound_s; T.orig_s = t_orig_s; T.gbound = t_gbound;
     T.idtab = t_idtab;
+    T.bound32 = t_bound32; T.bound32_s = t_bound32_s; T.gbound32 = t_gbound32;
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -906,7 +1031,8 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // per wave: [0] closest passes, [1] closest passes with an unbounded bundle, [2] exact tests in
     // closest passes, [3] shadow passes, [4] shadow passes unbounded, [5] exact tests in shadow passes
-    unsigned diag_c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // [8] groups expanded in closest passes, [9] in shadow passes, [10] object-level cull survivors (closest), [11] (shadow)
+    unsigned diag_c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     STAMP(0);
 
@@ -1005,7 +1131,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     DIAG(2, 1u);
                     if (tracing) closest_world(kind, m, ro, rd, j, best, hidx, hroot);
                     return true;
-                }, ro, rd, NoSkip{}, DIAG_PTR(6));
+                }, ro, rd, NoSkip{}, DIAG_PTR(6), DIAG_PTR(8), DIAG_PTR(10));
 #endif
             } else if (SRC == SRC_CULL2 && !PROBE && shared_origin && first) {
                 // primary rays of a large world: start at the apex, unit direction -> ordered walk with early stop
@@ -1013,13 +1139,13 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     DIAG(2, 1u);
                     if (tracing) closest_world(kind, m, ro, rd, j, best, hidx, hroot);
                     return true;
-                }, ro, rd, [&](float key) { return ballot(tracing && !(best < (double)key)) == 0ull; });
+                }, ro, rd, [&](float key) { return ballot(tracing && !(best < (double)key)) == 0ull; }, nullptr, DIAG_PTR(8), DIAG_PTR(10));
             } else {
                 for_each_object<SRC>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
                     DIAG(2, 1u);
                     if (tracing) closest_world(kind, m, ro, rd, j, best, hidx, hroot);
                     return true;
-                });
+                }, ro, rd, NoSkip{}, nullptr, DIAG_PTR(8), DIAG_PTR(10));
             }
             const bool hit = tracing && hidx >= 0;
             STAMP(3); // closest hit found
@@ -1158,7 +1284,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     if (occludes_world(kind, m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
                 }
                 return ballot(sh_pending) != 0ull;
-            }, over, sdir, NoSkip{}, DIAG_PTR(7));
+            }, over, sdir, NoSkip{}, DIAG_PTR(7), DIAG_PTR(9), DIAG_PTR(11));
 
             STAMP(6); // shadow resolved
             // keep the material / pattern loads of the lighting stage BELOW the shadow loop: hoisted
@@ -1470,7 +1596,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             if (c_resample) atomicAdd(slot + CNT_RESAMPLE, (unsigned long long)c_resample);
 #ifdef RTC_STAMPS
             for (int i = 0; i < 7; ++i) atomicAdd(slot + CNT_STAMP0 + i, stamp_t[i + 1] - stamp_t[i]);
-            for (int i = 0; i < 8; ++i) atomicAdd(slot + CNT_DIAG0 + i, (unsigned long long)diag_c[i]);
+            for (int i = 0; i < 16; ++i) atomicAdd(slot + CNT_DIAG0 + i, (unsigned long long)diag_c[i]);
 #endif
         }
     }
@@ -1554,7 +1680,7 @@ static hipError_t launch_kernel(const RenderParams &P, dim3 grid, size_t lds_byt
     }
     // e0/e1 (may be NULL) receive the dispatch's own begin/end timestamps: no marker packets on the stream
     hipExtLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK_OF(REFL)), lds_bytes, stream, e0, e1, 0, P, P.isect,
-                          P.kind, P.shade, P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound, P.idtab);
+                          P.kind, P.shade, P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound, P.idtab, P.bound32, P.bound32_s, P.gbound32);
     return hipGetLastError();
 }
 template <int SRC, bool REFL, bool REFR>

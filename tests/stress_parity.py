@@ -41,12 +41,41 @@ def big_world(seed):
     return w, cam
 
 
+def far_world(seed):
+    """The f32 wave-level cull's worst cases: the whole scene (objects, camera, light) translated far from the origin
+    (centres and apex lose up to 2^-24 of 1e3..1e7 when rounded to f32 — more than many of the radii), the scene scaled
+    by 1e-3..1e3, tiny spheres far away, a few hundred objects now and then (two-level walk)."""
+    rng = np.random.default_rng(seed)
+    u = lambda a, b: float(rng.uniform(a, b))
+    off = [0.0, 0.0, 0.0]
+    if rng.random() < 0.8:
+        mag = 10.0 ** u(2, 7)
+        off = [mag * u(-1, 1), mag * u(-1, 1) * 0.3, mag * u(-1, 1)]
+    sc = 10.0 ** u(-3, 3) if rng.random() < 0.5 else 1.0
+    P = lambda x, y, z: (off[0] + sc * x, off[1] + sc * y, off[2] + sc * z)
+    w = rtc.World(rtc.light(P(u(-8, 8), u(2, 12), u(-10, 0))))
+    n = int(rng.integers(300, 700)) if rng.random() < 0.25 else int(rng.integers(5, 60))
+    for i in range(n):
+        r = sc * (u(0.001, 0.02) if rng.random() < 0.3 else u(0.05, 1.5))
+        t = rtc.Matrix.identity().scaling(r, r * u(0.3, 1.7), r).rotation_z(u(0, 3)).translation(*P(u(-10, 10), u(-1, 6), u(-6, 40)))
+        m = rtc.material(color=(u(0, 1), u(0, 1), u(0, 1)), ambient=u(0, 0.3), diffuse=u(0.3, 0.9), specular=u(0, 0.5), shininess=u(5, 100),
+                         reflective=(u(0.1, 0.6) if rng.random() < 0.15 else 0.0))
+        try:
+            w.add_shape((rtc.cube if rng.random() < 0.15 else rtc.sphere)(t, m))
+        except rtc.RtcError:
+            pass  # singular by the reference's 1e-8 determinant rule
+    if rng.random() < 0.5:
+        w.add_shape(rtc.plane(rtc.Matrix.identity().translation(*P(0, u(-1, 0), 0)), rtc.material(specular=0.0, reflective=u(0, 0.4))))
+    cam = rtc.camera(56, 40, u(0.4, 1.6), rtc.Matrix.make_view_transform(P(u(-3, 3), u(0.5, 5), u(-10, -4)), P(u(-1, 1), u(0, 2), u(2, 8)), (0, 1, 0)))
+    return w, cam
+
+
 ctx = rtc.Context(0)
 bad = 0
 t0 = time.time()
 for k in range(n_worlds):
     seed = seed0 + k
-    w, cam = big_world(seed) if k % 3 == 2 else adversarial_scene(rtc, seed)
+    w, cam = far_world(seed) if k % 4 == 3 else (big_world(seed) if k % 3 == 2 else adversarial_scene(rtc, seed))
     dw = ctx.upload(w)
     got, st = dw.render(cam, rtc.MODE_RENDER_ASYNC, with_stats=True)
     brute, sb = dw.render(cam, rtc.MODE_RENDER_ASYNC, flags=1, with_stats=True)

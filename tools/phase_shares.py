@@ -29,16 +29,18 @@ ctx.reset_stats()
 dw.render_rows(cam, y0, y1, buf.data_ptr())
 ctx.synchronize()
 NW = 30 * ((y1 - y0 + 7) // 8) * 8  # waves launched: 8x8-pixel tiles, 32x8 blocks
-out = (C.c_ulonglong * 24)()
+out = (C.c_ulonglong * 32)()
 rtc.lib().rtc_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
-rtc.lib().rtc_debug_counters(ctx._h, out, 24)
+rtc.lib().rtc_debug_counters(ctx._h, out, 32)
 names = ["ray generation", "primary bundle", "primary cull + closest hit", "hit record + shadow ray", "shadow bundle",
          "shadow cull + any-hit", "lighting + store"]
 tot = sum(out[8 + i] for i in range(7))
 print(f"objects {len(w)}  kernel_ms(stamped) {ctx.last_kernel_ms():.3f}  waves {out[0] // 64 if out[0] else 0}")
 for i, nm in enumerate(names):
     print(f"  {nm:28s} {out[8 + i] / max(tot, 1) * 100:5.1f} %   {out[8 + i] / NW:9.0f} ticks/wave")
-d = [out[16 + i] for i in range(8)]
+d = [out[16 + i] for i in range(16)]
 print(f"per wave: closest passes {d[0] / NW:.2f} (unbounded bundle {d[1] / NW:.2f}), exact tests/closest pass {d[2] / max(d[0], 1):.2f}; "
       f"shadow passes {d[3] / NW:.2f} (unbounded {d[4] / NW:.2f}), exact tests/shadow pass {d[5] / max(d[3], 1):.2f}; "
       f"per-lane prefilter evaluations per wave: closest {d[6] / NW:.1f}, shadow {d[7] / NW:.1f}")
+print(f"two-level cull: groups expanded per closest pass {d[8] / max(d[0], 1):.2f}, per shadow pass {d[9] / max(d[3], 1):.2f}; "
+      f"object-level survivors per closest pass {d[10] / max(d[0], 1):.2f}, per shadow pass {d[11] / max(d[3], 1):.2f}")
