@@ -75,6 +75,11 @@
 #ifndef RTC_CULL_F32
 #define RTC_CULL_F32 1
 #endif
+// Per-apex bound tables (DevApex32): 1 = shadow bundles use the World's light tables, primary bundles of two-level
+// worlds the render's camera tables; 0 = every bundle takes the generic test.
+#ifndef RTC_APEX_TABLES
+#define RTC_APEX_TABLES 1
+#endif
 #ifndef RTC_GROUP_SLOTS
 #define RTC_GROUP_SLOTS 4
 #endif
@@ -568,6 +573,24 @@ template <bool KEYED = false> DEVI bool bundle_touches32(const Bundle &B, const 
     return !(perp2 * (B.fcos * B.fcos) > rhs * rhs * 1.00001f + 3e-6f * d2); // NaN-safe: keep unless provably far
 }
 
+// The fast form for bundles whose apex is one the World has a table for (DevApex32: the light, a camera origin): the
+// apex-dependent half of bundle_touches32 was evaluated per object by k_prep_apex; what is left is the cone test.
+// Valid iff the bundle's rays all start at that apex (rho = 0) and reach no farther than the table's spread.
+template <bool KEYED = false> DEVI bool apex_touches(const Bundle &B, const DevApex32 &a, float *key = nullptr) {
+#pragma clang fp contract(fast)
+    if constexpr (KEYED) *key = a.key;
+    if (B.off) return true;
+    if (!(a.Re < __builtin_inff())) return true;
+    const float wa = a.wx * B.fax + a.wy * B.fay + a.wz * B.faz;
+    if (wa < -a.Re) return false;
+    const float far = B.ftmax + a.Re;
+    if (a.d2 > far * far * 1.00001f) return false;
+    const float rhs = a.Re + (wa + fabsf(wa) * 2e-5f) * B.fsin;
+    if (rhs < 0.f) return false;
+    const float perp2 = a.d2 - wa * wa * 1.00002f;
+    return !(perp2 * (B.fcos * B.fcos) > rhs * rhs * 1.00001f + a.e2);
+}
+
 // Per-lane prefilter for INCOHERENT rays (reflection / refraction): can THIS lane's ray, for some
 // t >= 0, touch the object's bounding sphere? false => the exact test would find no entry with
 // t >= 0 for this lane. ~22 f64 instructions against 54+ for the exact test; the exact test is
@@ -666,7 +689,10 @@ DEVI int take_min_key(unsigned long long &mask, float key, float &kmin) {
 template <int SRC, bool LANE_FILTER = false, class PP, class F, class SK = NoSkip>
 DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool lane_needs, const Bundle &B, F &&f,
                           V3 fro = V3{0., 0., 0.}, V3 frd = V3{0., 0., 0.}, SK skip = SK{}, unsigned *nfilt = nullptr,
-                          unsigned *ngrp = nullptr, unsigned *nobj = nullptr) {
+                          unsigned *ngrp = nullptr, unsigned *nobj = nullptr, const DevApex32 *ao = nullptr,
+                          const DevApex32 *ag = nullptr) {
+    // ao / ag (wave-uniform, may be null): per-apex tables of the objects (in this variant's order) and of the groups,
+    // valid for THIS bundle (apex_touches) — the caller checked apex, rho and reach
     constexpr bool ORDERED = !__is_same(SK, NoSkip);
     if constexpr (SRC == SRC_CULL) {
         // One-level cull (small worlds): 64 objects at a time, each lane tests one object's sphere
@@ -677,7 +703,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
         for (uint32_t base = 0; base < P.n; base += 64u) {
             const uint32_t j = base + lane;
             bool cand = false;
-            if (j < P.n) cand = WAVE_CULL(false, B, T.bound, T.bound32, j, nullptr);
+            if (j < P.n) cand = ao ? apex_touches(B, ao[j]) : WAVE_CULL(false, B, T.bound, T.bound32, j, nullptr);
             unsigned long long mask = ballot(cand);
             while (mask) {
                 const uint32_t jj = base + (uint32_t)__builtin_ctzll(mask);
@@ -704,7 +730,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
             const uint32_t j = base + lane;
             bool cand = false;
             float okey = 0.f;
-            if (j < P.n) cand = WAVE_CULL(ORDERED, B, T.bound_s, T.bound32_s, j, &okey);
+            if (j < P.n) cand = ao ? apex_touches<ORDERED>(B, ao[j], &okey) : WAVE_CULL(ORDERED, B, T.bound_s, T.bound32_s, j, &okey);
             unsigned long long mask = ballot(cand);
             while (mask) {
                 uint32_t jj;
@@ -736,7 +762,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
                 const uint32_t g = gbase + sl * 64u + lane;
                 bool gc = false;
                 float gkey = 0.f;
-                if (gbase + sl * 64u < P.ngroups && g < P.ngroups) gc = WAVE_CULL(ORDERED, B, T.gbound, T.gbound32, g, &gkey);
+                if (gbase + sl * 64u < P.ngroups && g < P.ngroups) gc = ag ? apex_touches<ORDERED>(B, ag[g], &gkey) : WAVE_CULL(ORDERED, B, T.gbound, T.gbound32, g, &gkey);
                 kb[sl] = gc ? __builtin_bit_cast(unsigned, gkey) : 0xffffffffu;
                 gm[sl] = ballot(gc);
             }
@@ -773,7 +799,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
             const uint32_t g = gbase + lane;
             bool gc = false;
             float gkey = 0.f;
-            if (g < P.ngroups) gc = WAVE_CULL(ORDERED, B, T.gbound, T.gbound32, g, &gkey);
+            if (g < P.ngroups) gc = ag ? apex_touches<ORDERED>(B, ag[g], &gkey) : WAVE_CULL(ORDERED, B, T.gbound, T.gbound32, g, &gkey);
             unsigned long long gmask = ballot(gc);
             while (gmask) {
                 uint32_t gsel;
@@ -1134,12 +1160,17 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 }, ro, rd, NoSkip{}, DIAG_PTR(6), DIAG_PTR(8), DIAG_PTR(10));
 #endif
             } else if (SRC == SRC_CULL2 && !PROBE && shared_origin && first) {
-                // primary rays of a large world: start at the apex, unit direction -> ordered walk with early stop
+                // primary rays of a large world: start at the apex, unit direction -> ordered walk with early stop; the
+                // camera's per-apex tables (this view's) take the apex-dependent half of the bound test out of the walk
+                const auto &Pt = KP(P_arg);
+                const DevApex32 *cam_grp = Pt.cam_tab ? Pt.cam_tab + (size_t)view * Pt.cam_stride : nullptr;
+                const DevApex32 *cam_obj = cam_grp ? cam_grp + Pt.ngroups : nullptr;
                 for_each_object<SRC, false>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
                     DIAG(2, 1u);
                     if (tracing) closest_world(kind, m, ro, rd, j, best, hidx, hroot);
                     return true;
-                }, ro, rd, [&](float key) { return ballot(tracing && !(best < (double)key)) == 0ull; }, nullptr, DIAG_PTR(8), DIAG_PTR(10));
+                }, ro, rd, [&](float key) { return ballot(tracing && !(best < (double)key)) == 0ull; }, nullptr, DIAG_PTR(8), DIAG_PTR(10),
+                   cam_obj, cam_grp);
             } else {
                 for_each_object<SRC>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
                     DIAG(2, 1u);
@@ -1278,13 +1309,23 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             STAMP(5); // shadow bundle built
             DIAG(3, ballot(hit) != 0ull ? 1u : 0u);
             DIAG(4, (ballot(hit) != 0ull && Bs.off) ? 1u : 0u);
+            // every shadow bundle's apex is the light: the World's light tables apply when the segments are no longer
+            // than the reach they were built for
+            const DevApex32 *lt_obj = nullptr, *lt_grp = nullptr;
+            if constexpr (IS_CULL(SRC)) {
+                const auto &Pl = KP(P_arg);
+                if (RTC_APEX_TABLES && !Bs.off && Bs.ftmax <= Pl.shadow_S0) {
+                    lt_obj = (SRC == SRC_CULL2) ? Pl.light_obj_s : Pl.light_obj;
+                    lt_grp = Pl.light_grp;
+                }
+            }
             for_each_object<SRC, RTC_SHADOW_LANE_FILTER(SRC, REFL)>(P, T, L, sh_pending, Bs, [&](int j, auto m, uint32_t kind, auto pr) {
                 DIAG(5, 1u);
                 if (sh_pending) {
                     if (occludes_world(kind, m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
                 }
                 return ballot(sh_pending) != 0ull;
-            }, over, sdir, NoSkip{}, DIAG_PTR(7), DIAG_PTR(9), DIAG_PTR(11));
+            }, over, sdir, NoSkip{}, DIAG_PTR(7), DIAG_PTR(9), DIAG_PTR(11), lt_obj, lt_grp);
 
             STAMP(6); // shadow resolved
             // keep the material / pattern loads of the lighting stage BELOW the shadow loop: hoisted
@@ -1632,6 +1673,47 @@ __global__ void k_arith(uint32_t op, const double *a, const double *b, uint32_t 
     default: r = fmod(a[i], 2.0); break;
     }
     out[i] = r;
+}
+
+// Per-apex tables: bundle_touches32's apex-dependent half for `count` bounds seen from one apex, for bundles with
+// rho = 0 and reach <= spread (see DevApex32 / apex_touches). Same arithmetic, same margins as bundle_touches32.
+__global__ void __launch_bounds__(256) k_prep_apex(const DevBound32 *__restrict__ b, uint32_t count, double ax, double ay, double az,
+                                                    float spread, DevApex32 *__restrict__ out) {
+#pragma clang fp contract(fast)
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const DevBound32 o = b[i];
+    DevApex32 a;
+    const float px = (float)ax, py = (float)ay, pz = (float)az;
+    const float fep = (fabsf(px) + fabsf(py) + fabsf(pz)) * 2e-7f + 1e-30f;
+    a.wx = o.cx - px; a.wy = o.cy - py; a.wz = o.cz - pz;
+    const float l1 = fabsf(a.wx) + fabsf(a.wy) + fabsf(a.wz);
+    const float epos = o.ec + fep;
+    const float Dub = (l1 + spread) * 1.000001f + epos;
+    const float r_eff = o.r + o.r * (o.k * Dub * (o.cn + Dub)) * 1.00001f;
+    float Re = r_eff * 1.00001f + 4e-6f * l1 + epos;
+    a.d2 = a.wx * a.wx + a.wy * a.wy + a.wz * a.wz;
+    float key = 0.f;
+    if (!(o.r < __builtin_inff()) || !(a.d2 < 1e30f) || !(Re < 1e30f) || a.d2 <= Re * Re || !(fep < 1e30f)) {
+        Re = __builtin_inff(); // always a candidate
+        a.wx = a.wy = a.wz = 0.f;
+        a.d2 = 0.f;
+    } else {
+        const float dist = __builtin_sqrtf(a.d2) * 0.99999f, rad = Re * 1.00001f;
+        key = fmaxf(0.f, (dist - rad) * 0.99999f);
+    }
+    a.Re = Re;
+    a.key = key;
+    a.e2 = 3e-6f * a.d2;
+    a._pad = 0.f;
+    out[i] = a;
+}
+
+extern "C" hipError_t rtc_launch_prep_apex(const DevBound32 *b, uint32_t count, double ax, double ay, double az, float spread,
+                                           DevApex32 *out, hipStream_t stream) {
+    if (count == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_prep_apex, dim3((count + 255u) / 256u), dim3(256), 0, stream, b, count, ax, ay, az, spread, out);
+    return hipGetLastError();
 }
 
 // Un-deal (rtc_group_render, member 0): the gather leaves N chunks, chunk p = member p's packed bands of
