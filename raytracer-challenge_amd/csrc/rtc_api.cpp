@@ -227,10 +227,6 @@ void fill_world(RenderParams &P, const rtc_world *w) {
     P.bound32 = w->d_bound32;
     P.bound32_s = w->d_bound32_s;
     P.gbound32 = w->d_gbound32;
-    P.light_obj = w->d_light_obj;
-    P.light_obj_s = w->d_light_obj_s;
-    P.light_grp = w->d_light_grp;
-    P.shadow_S0 = w->shadow_S0;
     P.ngroups = w->ngroups;
     P.n = w->n;
     for (int i = 0; i < 3; ++i) {
@@ -474,28 +470,6 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
          hipMemcpy(w->d_bound32_s, bound32_s.data(), sizeof(DevBound32) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_gbound32, gbound32.data(), sizeof(DevBound32) * gbound32.size(), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(w->d_prim, 0, sizeof(DevPrim) * na) == hipSuccess;
-    // per-apex tables. The light's: every shadow bundle starts there (is_shadowed_by_light shape.rs:716-720); valid for
-    // segments up to shadow_S0 = twice the farthest bounded object's far side as seen from the light.
-    if (ok) {
-        double far = 0.;
-        for (uint32_t i = 0; i < n; ++i)
-            if (std::isfinite(bound[i].r)) {
-                const double dx = bound[i].cx - light->position[0], dy = bound[i].cy - light->position[1], dz = bound[i].cz - light->position[2];
-                far = std::fmax(far, std::sqrt(dx * dx + dy * dy + dz * dz) + bound[i].r);
-            }
-        const double s0 = 2. * far;
-        w->shadow_S0 = (std::isfinite(s0) && s0 < 1e30) ? std::nextafterf((float)s0, INFINITY) : 0.f;
-        w->cam_stride = (n > 256) ? (uint32_t)gbound.size() + na : 0u; // camera tables only for two-level worlds
-        ok = hipMalloc(&w->d_light_obj, sizeof(DevApex32) * na) == hipSuccess &&
-             hipMalloc(&w->d_light_obj_s, sizeof(DevApex32) * na) == hipSuccess &&
-             hipMalloc(&w->d_light_grp, sizeof(DevApex32) * gbound.size()) == hipSuccess &&
-             (w->cam_stride == 0 || hipMalloc(&w->d_cam_tab, sizeof(DevApex32) * (size_t)w->cam_stride * RTC_MAX_VIEWS) == hipSuccess);
-        const double *L = light->position;
-        ok = ok && rtc_launch_prep_apex(w->d_bound32, na, L[0], L[1], L[2], w->shadow_S0, w->d_light_obj, ctx->stream) == hipSuccess &&
-             rtc_launch_prep_apex(w->d_bound32_s, na, L[0], L[1], L[2], w->shadow_S0, w->d_light_obj_s, ctx->stream) == hipSuccess &&
-             rtc_launch_prep_apex(w->d_gbound32, (uint32_t)gbound.size(), L[0], L[1], L[2], w->shadow_S0, w->d_light_grp, ctx->stream) == hipSuccess &&
-             hipStreamSynchronize(ctx->stream) == hipSuccess;
-    }
     if (!ok) {
         rtc_world_destroy(w);
         return RTC_ERR_DEVICE;
@@ -524,10 +498,6 @@ void rtc_world_destroy(rtc_world *w) {
     if (w->d_bound32) (void)hipFree(w->d_bound32);
     if (w->d_bound32_s) (void)hipFree(w->d_bound32_s);
     if (w->d_gbound32) (void)hipFree(w->d_gbound32);
-    if (w->d_light_obj) (void)hipFree(w->d_light_obj);
-    if (w->d_light_obj_s) (void)hipFree(w->d_light_obj_s);
-    if (w->d_light_grp) (void)hipFree(w->d_light_grp);
-    if (w->d_cam_tab) (void)hipFree(w->d_cam_tab);
     delete w;
 }
 
@@ -567,18 +537,6 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     // per-render camera tables of two-level worlds: every primary bundle of view v starts at that camera's origin
     // (transform_point(view_inv, (0,0,0)) camera.rs:72, the kernel's own expression), so the apex-dependent half of the
     // wave-level bound test is evaluated once per object here instead of once per (wave, object)
-    if (src == SRC_CULL2 && w->d_cam_tab && w->cam_stride) {
-        for (uint32_t v = 0; v < nviews; ++v) {
-            const double *m = P.views[v].vinv;
-            const double ox = m[0] * 0. + m[1] * 0. + m[2] * 0. + m[3], oy = m[4] * 0. + m[5] * 0. + m[6] * 0. + m[7],
-                         oz = m[8] * 0. + m[9] * 0. + m[10] * 0. + m[11];
-            DevApex32 *tab = w->d_cam_tab + (size_t)v * w->cam_stride;
-            HIP_TRY(rtc_launch_prep_apex(w->d_gbound32, w->ngroups, ox, oy, oz, 0.f, tab, ctx->stream));
-            HIP_TRY(rtc_launch_prep_apex(w->d_bound32_s, w->n, ox, oy, oz, 0.f, tab + w->ngroups, ctx->stream));
-        }
-        P.cam_tab = w->d_cam_tab;
-        P.cam_stride = w->cam_stride;
-    }
     // per-render prologue table of the brute-force variants (the culled kernels do not use it)
     if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.views[0].vinv, ctx->stream));
     // start/stop events cost ~9 us of host time and ~5 us of GPU time per launch (measured): callers

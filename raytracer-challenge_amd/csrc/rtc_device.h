@@ -61,16 +61,6 @@ struct DevBound32 {
     float k, cn, ec, _pad;
 };
 
-// A bound as seen from ONE fixed apex (the light for every shadow bundle of a World; a camera's origin for every primary
-// bundle of a render): everything in bundle_touches32 that does not depend on the bundle's axis and half-angle, evaluated
-// once per object (k_prep_apex) instead of once per (wave, object). Valid for bundles whose rays all start at that apex
-// (rho = 0) and whose reach is at most the `spread` the table was built for. Re = +inf: always a candidate (unbounded
-// object, apex inside the inflated sphere, or overflow).
-struct DevApex32 {
-    float wx, wy, wz, Re; // centre - apex, inflated radius
-    float d2, key, e2, _pad; // |w|^2, lower bound of the distance apex -> sphere (ordered walks), 3e-6 * d2
-};
-
 // Rounding note. The cull must never drop an object for which the REFERENCE ARITHMETIC reports an
 // intersection — including intersections that exist only because of rounding. The sphere test
 // evaluates disc = b*b - 4*a*c with b^2 and 4ac of size ~4a|o'|^2 (o' = object-space ray origin);
@@ -129,12 +119,6 @@ struct RenderParams {
     const DevBound32 *bound32;   // [n]       f32 twins of bound / bound_s / gbound for the wave-level cull
     const DevBound32 *bound32_s; // [n]
     const DevBound32 *gbound32;  // [ngroups]
-    // per-apex tables (DevApex32): the light's (built once per World, valid for shadow segments up to shadow_S0 long) in
-    // insertion order, Morton order and for the groups; the cameras' (built per render for two-level worlds): view v at
-    // cam_tab + v * cam_stride, groups first, then the objects in Morton order. nullptr: not available.
-    const DevApex32 *light_obj, *light_obj_s, *light_grp, *cam_tab;
-    uint32_t cam_stride;
-    float shadow_S0;
     uint32_t ngroups;
     uint32_t n;
     uint32_t tile_cap; // objects per LDS tile (LDS variants)

@@ -48,17 +48,12 @@ struct rtc_world {
     DevBound *d_gbound = nullptr;
     DevIdEntry *d_idtab = nullptr;
     DevBound32 *d_bound32 = nullptr, *d_bound32_s = nullptr, *d_gbound32 = nullptr;
-    DevApex32 *d_light_obj = nullptr, *d_light_obj_s = nullptr, *d_light_grp = nullptr, *d_cam_tab = nullptr;
-    uint32_t cam_stride = 0;
-    float shadow_S0 = 0.f;
     uint32_t ngroups = 0;
     rtc_light light{};
     bool any_refl = false, any_refr = false;
 };
 
 
-extern "C" hipError_t rtc_launch_prep_apex(const DevBound32 *b, uint32_t count, double ax, double ay, double az, float spread,
-                                           DevApex32 *out, hipStream_t stream);
 extern "C" hipError_t rtc_launch_undeal(const void *staging, void *canvas, uint32_t nranks, uint32_t nframes, uint32_t H,
                                         uint32_t rows_max, size_t row_bytes, hipStream_t stream);
 

@@ -62,26 +62,25 @@
 #ifndef RTC_PRIMARY_LANE_FILTER
 #define RTC_PRIMARY_LANE_FILTER(SRC) false
 #endif
-// Two-level cull, group level. 1 (default): one ROUND tests up to RTC_GROUP_SLOTS x 64 group spheres against the
-// bundle at once (their loads overlap) and, for ordered walks (primary rays of large worlds), queues the
-// survivors' keys in a wave-private LDS array: groups are then expanded nearest-first across the WHOLE round and
-// the walk stops at the first key no lane can use. 0: the round-1 form, 64 groups per step, each step walked
-// (and ordered) on its own before the next step's groups are even tested.
-#ifndef RTC_GROUP_QUEUE
-#define RTC_GROUP_QUEUE 1
-#endif
 // Wave-level cull arithmetic: 1 (default) = f32 test on the f32 bound tables (bundle_touches32: the bundle is an f32
-// object anyway; ~35 two-cycle instructions against ~50 four-cycle f64 ones per 64 objects), 0 = the round-1 f64 test.
+// object anyway), 0 = the round-1 f64 test.
 #ifndef RTC_CULL_F32
 #define RTC_CULL_F32 1
 #endif
-// Per-apex bound tables (DevApex32): 1 = shadow bundles use the World's light tables, primary bundles of two-level
-// worlds the render's camera tables; 0 = every bundle takes the generic test.
-#ifndef RTC_APEX_TABLES
-#define RTC_APEX_TABLES 1
-#endif
+// Shape of the cull walks. A round of the group level tests RTC_GROUP_SLOTS x 64 group spheres at once (ordered walks
+// then take the nearest key across the whole round), a round of the one-level cull RTC_OBJ_SLOTS x 64 object spheres,
+// and RTC_EXPAND_K surviving groups are expanded together. Measured on MI355X (ms per frame, 8 frames per launch):
+// slots/objslots/K = 1/1/1: C3 0.234, C5 5.07, north star 0.0696; 4/2/2: 0.259 / 5.63 / 0.0724; 4/4/4: 0.274 / 5.99 / 0.0718.
+// Batching the walks buys nothing: these kernels are bound by VALU issue slots, not by the length of the
+// load -> test -> ballot dependency chains, and the wider rounds cost instructions and registers. Defaults 1/1/1.
 #ifndef RTC_GROUP_SLOTS
-#define RTC_GROUP_SLOTS 4
+#define RTC_GROUP_SLOTS 1
+#endif
+#ifndef RTC_OBJ_SLOTS
+#define RTC_OBJ_SLOTS 1
+#endif
+#ifndef RTC_EXPAND_K
+#define RTC_EXPAND_K 1
 #endif
 #ifndef RTC_TILE_ORDER
 // Workgroup id -> tile. The hardware deals consecutive workgroup ids round-robin over the 8 XCDs.
@@ -573,24 +572,6 @@ template <bool KEYED = false> DEVI bool bundle_touches32(const Bundle &B, const 
     return !(perp2 * (B.fcos * B.fcos) > rhs * rhs * 1.00001f + 3e-6f * d2); // NaN-safe: keep unless provably far
 }
 
-// The fast form for bundles whose apex is one the World has a table for (DevApex32: the light, a camera origin): the
-// apex-dependent half of bundle_touches32 was evaluated per object by k_prep_apex; what is left is the cone test.
-// Valid iff the bundle's rays all start at that apex (rho = 0) and reach no farther than the table's spread.
-template <bool KEYED = false> DEVI bool apex_touches(const Bundle &B, const DevApex32 &a, float *key = nullptr) {
-#pragma clang fp contract(fast)
-    if constexpr (KEYED) *key = a.key;
-    if (B.off) return true;
-    if (!(a.Re < __builtin_inff())) return true;
-    const float wa = a.wx * B.fax + a.wy * B.fay + a.wz * B.faz;
-    if (wa < -a.Re) return false;
-    const float far = B.ftmax + a.Re;
-    if (a.d2 > far * far * 1.00001f) return false;
-    const float rhs = a.Re + (wa + fabsf(wa) * 2e-5f) * B.fsin;
-    if (rhs < 0.f) return false;
-    const float perp2 = a.d2 - wa * wa * 1.00002f;
-    return !(perp2 * (B.fcos * B.fcos) > rhs * rhs * 1.00001f + a.e2);
-}
-
 // Per-lane prefilter for INCOHERENT rays (reflection / refraction): can THIS lane's ray, for some
 // t >= 0, touch the object's bounding sphere? false => the exact test would find no entry with
 // t >= 0 for this lane. ~22 f64 instructions against 54+ for the exact test; the exact test is
@@ -689,132 +670,150 @@ DEVI int take_min_key(unsigned long long &mask, float key, float &kmin) {
 template <int SRC, bool LANE_FILTER = false, class PP, class F, class SK = NoSkip>
 DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool lane_needs, const Bundle &B, F &&f,
                           V3 fro = V3{0., 0., 0.}, V3 frd = V3{0., 0., 0.}, SK skip = SK{}, unsigned *nfilt = nullptr,
-                          unsigned *ngrp = nullptr, unsigned *nobj = nullptr, const DevApex32 *ao = nullptr,
-                          const DevApex32 *ag = nullptr) {
-    // ao / ag (wave-uniform, may be null): per-apex tables of the objects (in this variant's order) and of the groups,
-    // valid for THIS bundle (apex_touches) — the caller checked apex, rho and reach
+                          unsigned *ngrp = nullptr, unsigned *nobj = nullptr) {
     constexpr bool ORDERED = !__is_same(SK, NoSkip);
     if constexpr (SRC == SRC_CULL) {
-        // One-level cull (small worlds): 64 objects at a time, each lane tests one object's sphere
-        // against the wave's bundle; the ballot mask is walked in ascending (= insertion) order and
-        // the survivors get the exact test, their records fetched by uniform index (scalar cache).
+        // One-level cull (small worlds): up to RTC_OBJ_SLOTS x 64 objects per round, each lane tests one object's sphere of
+        // every slot against the wave's bundle (the slots' loads are in flight together: one load -> test -> ballot
+        // dependency chain per round instead of one per 64 objects); the ballot masks are walked in ascending
+        // (= insertion) order and the survivors get the exact test, their records fetched by uniform index (scalar cache).
         if (ballot(lane_needs) == 0ull) return;
         const uint32_t lane = threadIdx.x & 63u;
-        for (uint32_t base = 0; base < P.n; base += 64u) {
-            const uint32_t j = base + lane;
-            bool cand = false;
-            if (j < P.n) cand = ao ? apex_touches(B, ao[j]) : WAVE_CULL(false, B, T.bound, T.bound32, j, nullptr);
-            unsigned long long mask = ballot(cand);
-            while (mask) {
-                const uint32_t jj = base + (uint32_t)__builtin_ctzll(mask);
-                mask &= mask - 1ull;
-                if constexpr (LANE_FILTER) {
-                    DIAG_FILTER(nfilt);
-                    if (ballot(lane_needs && ray_touches(fro, frd, T.bound[jj])) == 0ull) continue;
+        constexpr uint32_t OS = RTC_OBJ_SLOTS;
+        for (uint32_t base = 0; base < P.n; base += 64u * OS) {
+            unsigned long long masks[OS];
+#pragma unroll
+            for (uint32_t sl = 0; sl < OS; ++sl) {
+                const uint32_t j = base + sl * 64u + lane;
+                bool cand = false;
+                if (base + sl * 64u < P.n && j < P.n) cand = WAVE_CULL(false, B, T.bound, T.bound32, j, nullptr);
+                masks[sl] = ballot(cand);
+            }
+#pragma unroll
+            for (uint32_t sl = 0; sl < OS; ++sl) {
+                unsigned long long mask = masks[sl];
+                while (mask) {
+                    const uint32_t jj = base + sl * 64u + (uint32_t)__builtin_ctzll(mask);
+                    mask &= mask - 1ull;
+                    if constexpr (LANE_FILTER) {
+                        DIAG_FILTER(nfilt);
+                        if (ballot(lane_needs && ray_touches(fro, frd, T.bound[jj])) == 0ull) continue;
+                    }
+                    const DevIsect *rec = T.isect + jj;
+                    if (!f((int)jj, rec->m, T.kind[jj], (const double *)nullptr)) return;
                 }
-                const DevIsect *rec = T.isect + jj;
-                if (!f((int)jj, rec->m, T.kind[jj], (const double *)nullptr)) return;
             }
         }
     } else if constexpr (SRC == SRC_CULL2) {
         // Two-level cull (large worlds) over the Morton-sorted tables. Level 1: group spheres against the wave's
-        // bundle, one per lane. Level 2, per surviving group: its 64 objects, one object sphere per lane. Objects
-        // are not visited in insertion order here, so the callback receives the insertion index and the tie-break
-        // compares it (closer()).
+        // bundle, one per lane and slot. Level 2: the 64 objects of surviving groups, one object sphere per lane —
+        // RTC_EXPAND_K groups per round, their bounds loaded and tested together (one dependency chain per round).
+        // Objects are not visited in insertion order here, so the callback receives the insertion index and the
+        // tie-break compares it (closer()).
         if (ballot(lane_needs) == 0ull) return;
         const uint32_t lane = threadIdx.x & 63u;
-        // level 2: the objects of group `gidx`; returns false when the walk is over (callback said so)
-        auto expand = [&](uint32_t gidx) -> bool {
-            DIAG_FILTER(ngrp);
-            const uint32_t base = gidx * 64u;
-            const uint32_t j = base + lane;
-            bool cand = false;
-            float okey = 0.f;
-            if (j < P.n) cand = ao ? apex_touches<ORDERED>(B, ao[j], &okey) : WAVE_CULL(ORDERED, B, T.bound_s, T.bound32_s, j, &okey);
-            unsigned long long mask = ballot(cand);
-            while (mask) {
-                uint32_t jj;
-                if constexpr (ORDERED) {
-                    float kmin;
-                    jj = base + (uint32_t)take_min_key(mask, okey, kmin);
-                    if (skip(kmin)) break;
-                } else {
-                    jj = base + (uint32_t)__builtin_ctzll(mask);
-                    mask &= mask - 1ull;
+        constexpr uint32_t SLOTS = RTC_GROUP_SLOTS, K = RTC_EXPAND_K;
+        // level 2 for the `cnt` (<= K) groups gidx[0..cnt); returns false when the walk is over (callback said so)
+        auto expand = [&](const uint32_t (&gidx)[K], uint32_t cnt) -> bool {
+            unsigned long long masks[K];
+            float okey[K];
+#pragma unroll
+            for (uint32_t k = 0; k < K; ++k) {
+                bool cand = false;
+                okey[k] = 0.f;
+                if (k < cnt) {
+                    DIAG_FILTER(ngrp);
+                    const uint32_t j = gidx[k] * 64u + lane;
+                    if (j < P.n) cand = WAVE_CULL(ORDERED, B, T.bound_s, T.bound32_s, j, &okey[k]);
                 }
-                DIAG_FILTER(nobj);
-                if constexpr (LANE_FILTER) {
-                    DIAG_FILTER(nfilt);
-                    if (ballot(lane_needs && ray_touches(fro, frd, T.bound_s[jj])) == 0ull) continue;
+                masks[k] = ballot(cand);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < K; ++k) {
+                unsigned long long mask = masks[k];
+                const uint32_t base = (k < cnt ? gidx[k] : 0u) * 64u;
+                while (mask) {
+                    uint32_t jj;
+                    if constexpr (ORDERED) {
+                        float kmin;
+                        jj = base + (uint32_t)take_min_key(mask, okey[k], kmin);
+                        if (skip(kmin)) break;
+                    } else {
+                        jj = base + (uint32_t)__builtin_ctzll(mask);
+                        mask &= mask - 1ull;
+                    }
+                    DIAG_FILTER(nobj);
+                    if constexpr (LANE_FILTER) {
+                        DIAG_FILTER(nfilt);
+                        if (ballot(lane_needs && ray_touches(fro, frd, T.bound_s[jj])) == 0ull) continue;
+                    }
+                    const DevIsect *rec = T.isect_s + jj;
+                    if (!f((int)T.orig_s[jj], rec->m, T.kind_s[jj], (const double *)nullptr)) return false;
                 }
-                const DevIsect *rec = T.isect_s + jj;
-                if (!f((int)T.orig_s[jj], rec->m, T.kind_s[jj], (const double *)nullptr)) return false;
             }
             return true;
         };
-#if RTC_GROUP_QUEUE
-        constexpr uint32_t SLOTS = RTC_GROUP_SLOTS;
         for (uint32_t gbase = 0; gbase < P.ngroups; gbase += 64u * SLOTS) {
-            // one round: group (gbase + s*64 + lane) for s = 0..SLOTS-1, all loads in flight together
+            // one round of level 1: group (gbase + s*64 + lane) for s = 0..SLOTS-1, all loads in flight together
             unsigned kb[SLOTS];               // ordered: key bits (keys are >= 0: they order like unsigned); ~0u = no candidate
             unsigned long long gm[SLOTS];     // unordered: candidate masks
+#pragma unroll
             for (uint32_t sl = 0; sl < SLOTS; ++sl) {
                 const uint32_t g = gbase + sl * 64u + lane;
                 bool gc = false;
                 float gkey = 0.f;
-                if (gbase + sl * 64u < P.ngroups && g < P.ngroups) gc = ag ? apex_touches<ORDERED>(B, ag[g], &gkey) : WAVE_CULL(ORDERED, B, T.gbound, T.gbound32, g, &gkey);
+                if (gbase + sl * 64u < P.ngroups && g < P.ngroups)
+                    gc = WAVE_CULL(ORDERED, B, T.gbound, T.gbound32, g, &gkey);
                 kb[sl] = gc ? __builtin_bit_cast(unsigned, gkey) : 0xffffffffu;
                 gm[sl] = ballot(gc);
             }
             if constexpr (ORDERED) {
-                // the round's queue: nearest key first over ALL its slots. Each lane keeps its own minimum; the
-                // wave minimum picks the lane, that lane's slot is read back and struck out.
-                for (;;) {
-                    unsigned mine = kb[0];
-                    uint32_t msl = 0;
-                    for (uint32_t sl = 1; sl < SLOTS; ++sl)
-                        if (kb[sl] < mine) { mine = kb[sl]; msl = sl; }
-                    const unsigned minbits = ~wave_max_u32(~mine);
-                    if (minbits == 0xffffffffu) break;                                  // queue empty
-                    if (skip(__builtin_bit_cast(float, minbits))) break;                // ascending keys: the rest is out of reach too
-                    const int sel = (int)__builtin_ctzll(ballot(mine == minbits));
-                    const uint32_t ssl = (uint32_t)__builtin_amdgcn_readlane((int)msl, sel);
-                    for (uint32_t sl = 0; sl < SLOTS; ++sl)
-                        if (sl == ssl && lane == (uint32_t)sel) kb[sl] = 0xffffffffu;
-                    if (!expand(gbase + ssl * 64u + (uint32_t)sel)) return;
+                // the round's queue: nearest key first over ALL its slots. Each lane keeps its own minimum; the wave
+                // minimum picks the lane, that lane's slot is read back and struck out. K groups are taken per expansion.
+                for (bool more = true; more;) {
+                    uint32_t gidx[K];
+                    uint32_t cnt = 0;
+#pragma unroll
+                    for (uint32_t k = 0; k < K; ++k) {
+                        gidx[k] = 0u;
+                        if (!more) continue;
+                        unsigned mine = kb[0];
+                        uint32_t msl = 0;
+#pragma unroll
+                        for (uint32_t sl = 1; sl < SLOTS; ++sl)
+                            if (kb[sl] < mine) { mine = kb[sl]; msl = sl; }
+                        const unsigned minbits = ~wave_max_u32(~mine);
+                        // queue empty, or ascending keys: the rest is out of reach too
+                        if (minbits == 0xffffffffu || skip(__builtin_bit_cast(float, minbits))) { more = false; continue; }
+                        const int sel = (int)__builtin_ctzll(ballot(mine == minbits));
+                        const uint32_t ssl = (uint32_t)__builtin_amdgcn_readlane((int)msl, sel);
+#pragma unroll
+                        for (uint32_t sl = 0; sl < SLOTS; ++sl)
+                            if (sl == ssl && lane == (uint32_t)sel) kb[sl] = 0xffffffffu;
+                        gidx[k] = gbase + ssl * 64u + (uint32_t)sel;
+                        cnt = k + 1u;
+                    }
+                    if (cnt == 0u) break;
+                    if (!expand(gidx, cnt)) return;
                 }
             } else {
+                uint32_t gidx[K];
+                uint32_t cnt = 0;
+#pragma unroll
                 for (uint32_t sl = 0; sl < SLOTS; ++sl) {
                     unsigned long long gmask = gm[sl];
                     while (gmask) {
-                        const uint32_t gsel = (uint32_t)__builtin_ctzll(gmask);
+                        gidx[cnt++] = gbase + sl * 64u + (uint32_t)__builtin_ctzll(gmask);
                         gmask &= gmask - 1ull;
-                        if (!expand(gbase + sl * 64u + gsel)) return;
+                        if (cnt == K) {
+                            if (!expand(gidx, cnt)) return;
+                            cnt = 0;
+                        }
                     }
                 }
+                if (cnt != 0u && !expand(gidx, cnt)) return;
             }
         }
-#else
-        for (uint32_t gbase = 0; gbase < P.ngroups; gbase += 64u) {
-            const uint32_t g = gbase + lane;
-            bool gc = false;
-            float gkey = 0.f;
-            if (g < P.ngroups) gc = ag ? apex_touches<ORDERED>(B, ag[g], &gkey) : WAVE_CULL(ORDERED, B, T.gbound, T.gbound32, g, &gkey);
-            unsigned long long gmask = ballot(gc);
-            while (gmask) {
-                uint32_t gsel;
-                if constexpr (ORDERED) {
-                    float kmin;
-                    gsel = (uint32_t)take_min_key(gmask, gkey, kmin);
-                    if (skip(kmin)) break; // ascending keys: the rest of this step is out of reach too
-                } else {
-                    gsel = (uint32_t)__builtin_ctzll(gmask);
-                    gmask &= gmask - 1ull;
-                }
-                if (!expand(gbase + gsel)) return;
-            }
-        }
-#endif
     } else if constexpr (SRC == SRC_SMEM) {
         if (ballot(lane_needs) == 0ull) return;
         for (uint32_t j = 0; j < P.n; ++j) {
@@ -1160,17 +1159,12 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 }, ro, rd, NoSkip{}, DIAG_PTR(6), DIAG_PTR(8), DIAG_PTR(10));
 #endif
             } else if (SRC == SRC_CULL2 && !PROBE && shared_origin && first) {
-                // primary rays of a large world: start at the apex, unit direction -> ordered walk with early stop; the
-                // camera's per-apex tables (this view's) take the apex-dependent half of the bound test out of the walk
-                const auto &Pt = KP(P_arg);
-                const DevApex32 *cam_grp = Pt.cam_tab ? Pt.cam_tab + (size_t)view * Pt.cam_stride : nullptr;
-                const DevApex32 *cam_obj = cam_grp ? cam_grp + Pt.ngroups : nullptr;
+                // primary rays of a large world: start at the apex, unit direction -> ordered walk with early stop
                 for_each_object<SRC, false>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
                     DIAG(2, 1u);
                     if (tracing) closest_world(kind, m, ro, rd, j, best, hidx, hroot);
                     return true;
-                }, ro, rd, [&](float key) { return ballot(tracing && !(best < (double)key)) == 0ull; }, nullptr, DIAG_PTR(8), DIAG_PTR(10),
-                   cam_obj, cam_grp);
+                }, ro, rd, [&](float key) { return ballot(tracing && !(best < (double)key)) == 0ull; }, nullptr, DIAG_PTR(8), DIAG_PTR(10));
             } else {
                 for_each_object<SRC>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
                     DIAG(2, 1u);
@@ -1309,23 +1303,13 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             STAMP(5); // shadow bundle built
             DIAG(3, ballot(hit) != 0ull ? 1u : 0u);
             DIAG(4, (ballot(hit) != 0ull && Bs.off) ? 1u : 0u);
-            // every shadow bundle's apex is the light: the World's light tables apply when the segments are no longer
-            // than the reach they were built for
-            const DevApex32 *lt_obj = nullptr, *lt_grp = nullptr;
-            if constexpr (IS_CULL(SRC)) {
-                const auto &Pl = KP(P_arg);
-                if (RTC_APEX_TABLES && !Bs.off && Bs.ftmax <= Pl.shadow_S0) {
-                    lt_obj = (SRC == SRC_CULL2) ? Pl.light_obj_s : Pl.light_obj;
-                    lt_grp = Pl.light_grp;
-                }
-            }
             for_each_object<SRC, RTC_SHADOW_LANE_FILTER(SRC, REFL)>(P, T, L, sh_pending, Bs, [&](int j, auto m, uint32_t kind, auto pr) {
                 DIAG(5, 1u);
                 if (sh_pending) {
                     if (occludes_world(kind, m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
                 }
                 return ballot(sh_pending) != 0ull;
-            }, over, sdir, NoSkip{}, DIAG_PTR(7), DIAG_PTR(9), DIAG_PTR(11), lt_obj, lt_grp);
+            }, over, sdir, NoSkip{}, DIAG_PTR(7), DIAG_PTR(9), DIAG_PTR(11));
 
             STAMP(6); // shadow resolved
             // keep the material / pattern loads of the lighting stage BELOW the shadow loop: hoisted
@@ -1673,47 +1657,6 @@ __global__ void k_arith(uint32_t op, const double *a, const double *b, uint32_t 
     default: r = fmod(a[i], 2.0); break;
     }
     out[i] = r;
-}
-
-// Per-apex tables: bundle_touches32's apex-dependent half for `count` bounds seen from one apex, for bundles with
-// rho = 0 and reach <= spread (see DevApex32 / apex_touches). Same arithmetic, same margins as bundle_touches32.
-__global__ void __launch_bounds__(256) k_prep_apex(const DevBound32 *__restrict__ b, uint32_t count, double ax, double ay, double az,
-                                                    float spread, DevApex32 *__restrict__ out) {
-#pragma clang fp contract(fast)
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= count) return;
-    const DevBound32 o = b[i];
-    DevApex32 a;
-    const float px = (float)ax, py = (float)ay, pz = (float)az;
-    const float fep = (fabsf(px) + fabsf(py) + fabsf(pz)) * 2e-7f + 1e-30f;
-    a.wx = o.cx - px; a.wy = o.cy - py; a.wz = o.cz - pz;
-    const float l1 = fabsf(a.wx) + fabsf(a.wy) + fabsf(a.wz);
-    const float epos = o.ec + fep;
-    const float Dub = (l1 + spread) * 1.000001f + epos;
-    const float r_eff = o.r + o.r * (o.k * Dub * (o.cn + Dub)) * 1.00001f;
-    float Re = r_eff * 1.00001f + 4e-6f * l1 + epos;
-    a.d2 = a.wx * a.wx + a.wy * a.wy + a.wz * a.wz;
-    float key = 0.f;
-    if (!(o.r < __builtin_inff()) || !(a.d2 < 1e30f) || !(Re < 1e30f) || a.d2 <= Re * Re || !(fep < 1e30f)) {
-        Re = __builtin_inff(); // always a candidate
-        a.wx = a.wy = a.wz = 0.f;
-        a.d2 = 0.f;
-    } else {
-        const float dist = __builtin_sqrtf(a.d2) * 0.99999f, rad = Re * 1.00001f;
-        key = fmaxf(0.f, (dist - rad) * 0.99999f);
-    }
-    a.Re = Re;
-    a.key = key;
-    a.e2 = 3e-6f * a.d2;
-    a._pad = 0.f;
-    out[i] = a;
-}
-
-extern "C" hipError_t rtc_launch_prep_apex(const DevBound32 *b, uint32_t count, double ax, double ay, double az, float spread,
-                                           DevApex32 *out, hipStream_t stream) {
-    if (count == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_prep_apex, dim3((count + 255u) / 256u), dim3(256), 0, stream, b, count, ax, ay, az, spread, out);
-    return hipGetLastError();
 }
 
 // Un-deal (rtc_group_render, member 0): the gather leaves N chunks, chunk p = member p's packed bands of
