@@ -520,17 +520,18 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     P.counters = ctx->d_counters;
     P.rays = nullptr;
     P.remaining = RTC_MAX_REFLECTIONS; // render_pixel passes Camera::MAX_REFLECTIONS camera.rs:98
-    const uint32_t tile_w = RTC_TILE_W_OF(w->any_refl || w->any_refr);
-    P.grid_x = (cam->hsize + tile_w - 1u) / tile_w;
-    P.grid_y = grid_y;
-    P.band_stride = band_stride;
     int src;
     size_t lds_bytes;
     choose_source(ctx, w->n, flags, &src, &P.tile_cap, &lds_bytes);
+    const bool cull = src == SRC_CULL || src == SRC_CULL2, refl = w->any_refl || w->any_refr;
+    const uint32_t block = RTC_BLOCK_FOR(cull, refl, w->any_refr, false), tile_w = RTC_TILE_W_FOR(cull, refl, w->any_refr, false);
+    P.grid_x = (cam->hsize + tile_w - 1u) / tile_w;
+    P.grid_y = grid_y;
+    P.band_stride = band_stride;
     P.flags = flags;
     if (P.samples != 1u) { // the 4 sub-samples of every pixel wait in LDS for the resample test (camera.rs:108)
         P.aa_lds_off = (uint32_t)lds_bytes;
-        lds_bytes += (size_t)RTC_BLOCK_OF(w->any_refl || w->any_refr) * 15u * sizeof(double); // + the running sums
+        lds_bytes += (size_t)block * 15u * sizeof(double); // + the running sums
         // Camera::resample traces `antialiasing_samples` more rays (camera.rs:87); u8 in the reference
         P.resample_n = (flags & RTC_FLAG_AA_RESAMPLE) ? (cam->samples & 0xffu) : 0u;
     }
@@ -764,7 +765,7 @@ rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays
         P.nrays = n;
         P.remaining = remaining;
         P.hits = d_hits;
-        const uint32_t blk = RTC_BLOCK_OF(w->any_refl || w->any_refr);
+        const uint32_t blk = RTC_BLOCK_FOR(true, w->any_refl || w->any_refr, w->any_refr, true);
         P.grid_x = (n + blk - 1u) / blk;
         P.grid_y = 1;
         P.band_stride = 1;

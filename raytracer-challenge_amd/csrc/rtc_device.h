@@ -100,8 +100,16 @@ enum { RTC_MAX_VIEWS = 8 };
 #ifndef RTC_BLOCK_STACK
 #define RTC_BLOCK_STACK 64
 #endif
-#define RTC_BLOCK_OF(stack) ((stack) ? RTC_BLOCK_STACK : RTC_BLOCK)
-#define RTC_TILE_W_OF(stack) ((RTC_BLOCK_OF(stack) / 64u) * 8u)
+// K3, ray compaction between bounces (rtc_kernels.hip, COMPACT): reflection-only Worlds on the culled variants render with
+// TWO waves per workgroup, which merge their live rays into one wave once they fit (RTC_COMPACT = 1); 0 = one wave per
+// workgroup, no merging. Host grid and kernel must agree on the workgroup size: RTC_BLOCK_FOR.
+#ifndef RTC_COMPACT
+#define RTC_COMPACT 0
+#endif
+#define RTC_COMPACT_FOR(cull, refl, refr, probe) (RTC_COMPACT && (cull) && (refl) && !(refr) && !(probe))
+#define RTC_BLOCK_FOR(cull, refl, refr, probe) \
+    (((refl) || (refr)) ? (RTC_COMPACT_FOR(cull, refl, refr, probe) ? 128 : RTC_BLOCK_STACK) : RTC_BLOCK)
+#define RTC_TILE_W_FOR(cull, refl, refr, probe) ((RTC_BLOCK_FOR(cull, refl, refr, probe) / 64u) * 8u)
 
 struct RenderParams {
     const DevIsect *isect;

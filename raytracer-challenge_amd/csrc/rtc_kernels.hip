@@ -988,16 +988,20 @@ DEVI V3 combine(V3 surface, V3 reflected, V3 refracted, bool schlick, double R) 
 // PROBE = true is the rtc_color_at flavour (arbitrary rays in, colours + hit records out); the
 // render flavour (PROBE = false) never carries the hit record's extra vectors in registers.
 template <int SRC, bool REFL, bool REFR, bool PROBE>
-__global__ void __launch_bounds__(RTC_BLOCK_OF(REFL), (REFL ? RTC_WAVES_PER_SIMD_STACK : RTC_WAVES_PER_SIMD))
+__global__ void __launch_bounds__(RTC_BLOCK_FOR(IS_CULL(SRC), REFL, REFR, PROBE), (REFL ? RTC_WAVES_PER_SIMD_STACK : RTC_WAVES_PER_SIMD))
 k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const uint32_t *__restrict__ t_kind,
         const DevShade *__restrict__ t_shade, const DevPrim *__restrict__ t_prim, const DevBound *__restrict__ t_bound,
         const DevIsect *__restrict__ t_isect_s, const uint32_t *__restrict__ t_kind_s, const DevBound *__restrict__ t_bound_s,
         const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound, const DevIdEntry *__restrict__ t_idtab,
         const DevBound32 *__restrict__ t_bound32, const DevBound32 *__restrict__ t_bound32_s, const DevBound32 *__restrict__ t_gbound32) {
-    constexpr uint32_t BLOCK = RTC_BLOCK_OF(REFL), TILE_W = RTC_TILE_W_OF(REFL);
+    constexpr uint32_t BLOCK = RTC_BLOCK_FOR(IS_CULL(SRC), REFL, REFR, PROBE), TILE_W = RTC_TILE_W_FOR(IS_CULL(SRC), REFL, REFR, PROBE);
+    constexpr bool COMPACT = RTC_COMPACT_FOR(IS_CULL(SRC), REFL, REFR, PROBE); // K3: two waves, live rays merged between bounces
     extern __shared__ double lds_raw[];
     constexpr bool LDS_STACK = RTC_LDS_STACK && REFL && !REFR; // 32-byte frames in LDS (one wave per workgroup)
-    static_assert(!LDS_STACK || BLOCK == 64, "the LDS frame stack and the tile staged over it assume one wave per workgroup");
+    static_assert(!LDS_STACK || BLOCK == 64 || COMPACT, "the tile is staged over the LDS frame stack: one wave per workgroup, or a barrier first");
+    // K3 exchange area: live counts per wave (double-buffered by pass parity) and up to 32 rays in transit
+    __shared__ uint32_t k3_cnt[COMPACT ? 4 : 1];
+    __shared__ __attribute__((aligned(16))) double k3_xfer[COMPACT ? 7 * 32 : 1];
     __shared__ __attribute__((aligned(16))) double stack_lds[LDS_STACK ? RTC_MAX_STACK * 4 * BLOCK : 2];
     __shared__ __attribute__((aligned(16))) double stage_own[(PROBE || LDS_STACK) ? 2 : 8 * TILE_W * 3];     // the tile, canvas layout
     __shared__ __attribute__((aligned(16))) unsigned char stage_own8[(PROBE || LDS_STACK) ? 16 : 8 * TILE_W * 3];
@@ -1073,7 +1077,11 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
 
     typedef FrameT<REFR> Frame;
     Frame stack[(REFL && !LDS_STACK) ? RTC_MAX_STACK : 1];
-    double *const lstk = stack_lds + threadIdx.x; // LDS stack: level l, component c at lstk[(l*4 + c) * BLOCK]
+    // LDS stack: level l, component c of the ray OWNED by home thread `owner` at stack_lds[(l*4 + c) * BLOCK + owner]. Without
+    // K3 a ray never leaves its home lane (owner == threadIdx.x); with it the lane that traces a ray pushes onto, and finally
+    // unwinds, the owner's stack and leaves the pixel's colour in the owner's level-0 slot.
+    uint32_t owner = threadIdx.x;
+    double *lstk = stack_lds + owner;
 
     for (uint32_t s = 0; s < nsamples; ++s) {
         V3 ro, rd;
@@ -1112,8 +1120,57 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
 
         // Worlds without reflective / transparent materials (REFL == false) need exactly one pass per
         // primary ray; otherwise loop until every lane's frame stack has unwound.
+        if constexpr (COMPACT) { // every pixel's colour is collected from its owner's level-0 slot; BLACK until a ray says otherwise
+            owner = threadIdx.x;
+            lstk = stack_lds + owner;
+            lstk[0] = 0.; lstk[BLOCK] = 0.; lstk[2 * BLOCK] = 0.;
+        }
+        uint32_t k3_pass = 0;
         for (bool pass_again = true; pass_again;) {
-            if constexpr (REFL) {
+            if constexpr (COMPACT) {
+                // K3 — wavefront compaction between bounces. The workgroup's two waves publish how many rays each still
+                // traces (__ballot + popcount); once both have some and together they fit one wave, the wave with fewer
+                // hands its rays (origin, direction, remaining, stack depth, owner) over through LDS to the idle lanes of the
+                // other and stops issuing passes. A ray's frames and its pixel's colour stay with its OWNER (LDS stack,
+                // owner-indexed), so results are bit-identical whichever lane traces it. One barrier per pass (the counts
+                // are double-buffered by pass parity), one more at the hand-over, which happens at most once.
+                const unsigned long long live = ballot(tracing);
+                uint32_t *cnt = k3_cnt + ((k3_pass & 1u) << 1);
+                ++k3_pass;
+                if (lane == 0) cnt[wave] = popc64(live);
+                __syncthreads();
+                const uint32_t c0 = cnt[0], c1 = cnt[1];
+                if (c0 + c1 == 0u) break;
+                if (c0 != 0u && c1 != 0u && c0 + c1 <= 64u) {
+                    const uint32_t donor = (c1 <= c0) ? 1u : 0u, moving = donor ? c1 : c0;
+                    if (wave == donor) {
+                        if (tracing) {
+                            const uint32_t r = (uint32_t)__builtin_amdgcn_mbcnt_hi((unsigned)(live >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)live, 0u));
+                            k3_xfer[r] = ro.x; k3_xfer[32 + r] = ro.y; k3_xfer[64 + r] = ro.z;
+                            k3_xfer[96 + r] = rd.x; k3_xfer[128 + r] = rd.y; k3_xfer[160 + r] = rd.z;
+                            k3_xfer[192 + r] = __builtin_bit_cast(double, (unsigned long long)(uint32_t)rem | ((unsigned long long)(uint32_t)sp << 8) |
+                                                                              ((unsigned long long)owner << 16));
+                        }
+                        tracing = false;
+                    }
+                    __syncthreads();
+                    if (wave != donor) {
+                        const unsigned long long idle = ~live;
+                        const uint32_t r = (uint32_t)__builtin_amdgcn_mbcnt_hi((unsigned)(idle >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)idle, 0u));
+                        if (!tracing && r < moving) {
+                            ro = mk(k3_xfer[r], k3_xfer[32 + r], k3_xfer[64 + r]);
+                            rd = mk(k3_xfer[96 + r], k3_xfer[128 + r], k3_xfer[160 + r]);
+                            const unsigned long long pk = __builtin_bit_cast(unsigned long long, k3_xfer[192 + r]);
+                            rem = (int)(pk & 0xffu);
+                            sp = (int)((pk >> 8) & 0xffu);
+                            owner = (uint32_t)(pk >> 16);
+                            lstk = stack_lds + owner;
+                            tracing = true;
+                        }
+                    }
+                }
+                if (ballot(tracing) == 0ull) continue; // nothing to trace in this wave (handed over, or done): next barrier
+            } else if constexpr (REFL) {
                 bool any_tracing;
                 if constexpr (SRC == SRC_LDSN) any_tracing = __syncthreads_or(tracing ? 1 : 0) != 0;
                 else any_tracing = ballot(tracing) != 0ull;
@@ -1437,7 +1494,11 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 }
                 if constexpr (REFL) {
                     if (!relaunched) {
-                        result = val;
+                        if constexpr (COMPACT) { // the owner's stack is unwound: its level-0 slot now carries the pixel's colour
+                            lstk[0] = val.x; lstk[BLOCK] = val.y; lstk[2 * BLOCK] = val.z;
+                        } else {
+                            result = val;
+                        }
                         tracing = false;
                     }
                 }
@@ -1450,6 +1511,13 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             }
         }
 
+        if constexpr (COMPACT) {
+            // both waves are out of the pass loop (the break is taken on the same counts): collect every pixel's colour
+            // from its own slot; the second barrier frees the stack area for the tile that is staged over it
+            const double *mine = stack_lds + threadIdx.x;
+            result = mk(mine[0], mine[BLOCK], mine[2 * BLOCK]);
+            __syncthreads();
+        }
         if constexpr (PROBE) {
             if (in_range) {
                 double *o = KP(P_arg).out + (size_t)ray_index * 3;
@@ -1489,7 +1557,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     const auto &Pa = KP(P_arg);
                     lane_resample = trip && Pa.resample_n != 0u;
                     bool more;
-                    if constexpr (SRC == SRC_LDSN) more = __syncthreads_or(lane_resample ? 1 : 0) != 0; // same pass count for every wave
+                    if constexpr (SRC == SRC_LDSN || COMPACT) more = __syncthreads_or(lane_resample ? 1 : 0) != 0; // same pass count for every wave
                     else more = ballot(lane_resample) != 0ull;
                     if (more) nsamples = 4u + Pa.resample_n;
                     if (!lane_resample) acc = mean; // final: the mean of the four
@@ -1704,7 +1772,7 @@ static hipError_t launch_kernel(const RenderParams &P, dim3 grid, size_t lds_byt
         if (e != hipSuccess) return e;
     }
     // e0/e1 (may be NULL) receive the dispatch's own begin/end timestamps: no marker packets on the stream
-    hipExtLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK_OF(REFL)), lds_bytes, stream, e0, e1, 0, P, P.isect,
+    hipExtLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK_FOR(IS_CULL(SRC), REFL, REFR, PROBE)), lds_bytes, stream, e0, e1, 0, P, P.isect,
                           P.kind, P.shade, P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound, P.idtab, P.bound32, P.bound32_s, P.gbound32);
     return hipGetLastError();
 }
