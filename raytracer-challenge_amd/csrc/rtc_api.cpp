@@ -179,24 +179,6 @@ DevBound bound_of(const rtc_shape &s) {
     return b;
 }
 
-// f32 twin of a bound for the wave-level cull: every quantity the test treats as an upper bound is rounded up, and
-// `ec` covers the error of rounding the centre (<= 2^-24 relative per coordinate).
-DevBound32 bound32_of(const DevBound &b) {
-    DevBound32 o{0.f, 0.f, 0.f, INFINITY, 0.f, 0.f, 0.f, 0.f};
-    const double big = 1e30;
-    if (!(b.r < big) || !(std::fabs(b.cx) < big) || !(std::fabs(b.cy) < big) || !(std::fabs(b.cz) < big) || !(b.k < big) || !(b.cn < big))
-        return o;
-    auto up = [](double x) { return std::nextafterf((float)x, INFINITY); };
-    o.cx = (float)b.cx;
-    o.cy = (float)b.cy;
-    o.cz = (float)b.cz;
-    o.r = up(b.r * (1. + 1e-6));
-    o.k = up(std::fmax(b.k, 1e-30));
-    o.cn = up(b.cn);
-    o.ec = up(2e-7 * (std::fabs(b.cx) + std::fabs(b.cy) + std::fabs(b.cz)) + 1e-30);
-    return o;
-}
-
 void fill_camera(RenderParams &P, const rtc_camera *cam, uint32_t view = 0) {
     if (view == 0) {
         P.W = cam->hsize;
@@ -224,9 +206,6 @@ void fill_world(RenderParams &P, const rtc_world *w) {
     P.orig_s = w->d_orig_s;
     P.gbound = w->d_gbound;
     P.idtab = w->d_idtab;
-    P.bound32 = w->d_bound32;
-    P.bound32_s = w->d_bound32_s;
-    P.gbound32 = w->d_gbound32;
     P.ngroups = w->ngroups;
     P.n = w->n;
     for (int i = 0; i < 3; ++i) {
@@ -449,13 +428,7 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
               hipMalloc(&w->d_bound_s, sizeof(DevBound) * na) == hipSuccess &&
               hipMalloc(&w->d_orig_s, sizeof(uint32_t) * na) == hipSuccess &&
               hipMalloc(&w->d_gbound, sizeof(DevBound) * gbound.size()) == hipSuccess &&
-              hipMalloc(&w->d_idtab, sizeof(DevIdEntry) * na) == hipSuccess &&
-              hipMalloc(&w->d_bound32, sizeof(DevBound32) * na) == hipSuccess &&
-              hipMalloc(&w->d_bound32_s, sizeof(DevBound32) * na) == hipSuccess &&
-              hipMalloc(&w->d_gbound32, sizeof(DevBound32) * gbound.size()) == hipSuccess;
-    std::vector<DevBound32> bound32(na), bound32_s(na), gbound32(gbound.size());
-    for (uint32_t i = 0; i < na; ++i) { bound32[i] = bound32_of(bound[i]); bound32_s[i] = bound32_of(bound_s[i]); }
-    for (size_t i = 0; i < gbound.size(); ++i) gbound32[i] = bound32_of(gbound[i]);
+              hipMalloc(&w->d_idtab, sizeof(DevIdEntry) * na) == hipSuccess;
     ok = ok && hipMemcpy(w->d_isect, isect.data(), sizeof(DevIsect) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_kind, kind.data(), sizeof(uint32_t) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_shade, shade.data(), sizeof(DevShade) * na, hipMemcpyHostToDevice) == hipSuccess &&
@@ -466,9 +439,6 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
          hipMemcpy(w->d_orig_s, orig_s.data(), sizeof(uint32_t) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_gbound, gbound.data(), sizeof(DevBound) * gbound.size(), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_idtab, idtab.data(), sizeof(DevIdEntry) * na, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(w->d_bound32, bound32.data(), sizeof(DevBound32) * na, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(w->d_bound32_s, bound32_s.data(), sizeof(DevBound32) * na, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemcpy(w->d_gbound32, gbound32.data(), sizeof(DevBound32) * gbound32.size(), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(w->d_prim, 0, sizeof(DevPrim) * na) == hipSuccess;
     if (!ok) {
         rtc_world_destroy(w);
@@ -495,9 +465,6 @@ void rtc_world_destroy(rtc_world *w) {
     if (w->d_orig_s) (void)hipFree(w->d_orig_s);
     if (w->d_gbound) (void)hipFree(w->d_gbound);
     if (w->d_idtab) (void)hipFree(w->d_idtab);
-    if (w->d_bound32) (void)hipFree(w->d_bound32);
-    if (w->d_bound32_s) (void)hipFree(w->d_bound32_s);
-    if (w->d_gbound32) (void)hipFree(w->d_gbound32);
     delete w;
 }
 

@@ -52,15 +52,6 @@ struct DevBound {
     double k;             // 0.75e-14 * ||A||_F^2 (A = 3x3 of the stored inverse): rounding inflation
     double cn;            // |centre|: see the note on rounding below
 };
-// The same bound for the WAVE-LEVEL cull (bundle_touches), in f32: the bundle itself is built in f32, and the test runs
-// once per (lane, object) 64 objects at a time — it is most of a large world's instruction count. Conservative by
-// construction: r, k, cn are rounded UP, and `ec` >= the error of rounding the centre to f32 (2e-7 * |c|_1), which the
-// test adds to the radius together with the same term for the apex. r = +inf: never culled (as DevBound).
-struct DevBound32 {
-    float cx, cy, cz, r;
-    float k, cn, ec, _pad;
-};
-
 // Rounding note. The cull must never drop an object for which the REFERENCE ARITHMETIC reports an
 // intersection — including intersections that exist only because of rounding. The sphere test
 // evaluates disc = b*b - 4*a*c with b^2 and 4ac of size ~4a|o'|^2 (o' = object-space ray origin);
@@ -124,9 +115,6 @@ struct RenderParams {
     const uint32_t *orig_s;    // [n] sorted position -> insertion index (World.shapes order)
     const DevBound *gbound;    // [ngroups] sphere around each group of 64 sorted objects
     const DevIdEntry *idtab;   // [n] shapes in stable order of world_id (compute_refractive's container key)
-    const DevBound32 *bound32;   // [n]       f32 twins of bound / bound_s / gbound for the wave-level cull
-    const DevBound32 *bound32_s; // [n]
-    const DevBound32 *gbound32;  // [ngroups]
     uint32_t ngroups;
     uint32_t n;
     uint32_t tile_cap; // objects per LDS tile (LDS variants)

@@ -47,7 +47,6 @@ struct rtc_world {
     uint32_t *d_orig_s = nullptr;
     DevBound *d_gbound = nullptr;
     DevIdEntry *d_idtab = nullptr;
-    DevBound32 *d_bound32 = nullptr, *d_bound32_s = nullptr, *d_gbound32 = nullptr;
     uint32_t ngroups = 0;
     rtc_light light{};
     bool any_refl = false, any_refr = false;

@@ -62,11 +62,6 @@
 #ifndef RTC_PRIMARY_LANE_FILTER
 #define RTC_PRIMARY_LANE_FILTER(SRC) false
 #endif
-// Wave-level cull arithmetic: 1 (default) = f32 test on the f32 bound tables (bundle_touches32: the bundle is an f32
-// object anyway), 0 = the round-1 f64 test.
-#ifndef RTC_CULL_F32
-#define RTC_CULL_F32 1
-#endif
 // Shape of the cull walks. A round of the group level tests RTC_GROUP_SLOTS x 64 group spheres at once (ordered walks
 // then take the nearest key across the whole round), a round of the one-level cull RTC_OBJ_SLOTS x 64 object spheres,
 // and RTC_EXPAND_K surviving groups are expanded together. Measured on MI355X (ms per frame, 8 frames per launch):
@@ -383,9 +378,6 @@ struct Bundle {
                          // primary rays, rho for secondary rays, tmax for shadow segments, whose
                          // exact rays start at the far end)
     bool off;            // bundle could not be bounded: every object is a candidate
-    // the same bundle for the f32 test (bundle_touches32); everything but the apex is an f32 value to begin with
-    float fpx, fpy, fpz, fax, fay, faz, fcos, fsin, frho, ftmax, fspread;
-    float fep;           // >= the error of rounding the apex to f32 (2e-7 * |apex|_1)
 };
 
 // A wave-uniform double that the compiler would otherwise keep in two VGPRs: move it to SGPRs.
@@ -394,8 +386,6 @@ DEVI double uniform_f64(double x) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)u), hi = __builtin_amdgcn_readfirstlane((unsigned)(u >> 32));
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
-
-DEVI float uniform_f32(float x) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, x))); }
 
 DEVI bool finite3(V3 v) { return fabs(v.x) < __builtin_inf() && fabs(v.y) < __builtin_inf() && fabs(v.z) < __builtin_inf(); }
 
@@ -482,15 +472,6 @@ DEVI Bundle make_bundle(bool active, V3 apex, V3 o, V3 d, double reach) {
     B.tmax = uniform_f64((double)tmax);
     B.spread = REACH ? B.tmax : B.rho;
     if (!(B.spread < 1e300)) off = true; // shadow segment of unbounded length: do not cull
-    B.fpx = uniform_f32((float)apex.x); B.fpy = uniform_f32((float)apex.y); B.fpz = uniform_f32((float)apex.z);
-    B.fax = ax; B.fay = ay; B.faz = az;
-    B.fcos = uniform_f32(cosT); B.fsin = uniform_f32(sinT);
-    B.frho = uniform_f32(rho);
-    B.ftmax = uniform_f32(tmax);
-    B.fspread = REACH ? B.ftmax : B.frho;
-    const float pl1 = fabsf(B.fpx) + fabsf(B.fpy) + fabsf(B.fpz);
-    B.fep = pl1 * 2e-7f + 1e-30f;
-    if (!(pl1 < 1e30f)) off = true;
     B.off = off;
     return B;
 }
@@ -535,41 +516,6 @@ template <bool KEYED = false> DEVI bool bundle_touches(const Bundle &B, const De
     if (rhs < 0.) return false;
     const double perp2 = d2 - wa * wa * 1.00001;
     return !(perp2 * (B.cosT * B.cosT) > rhs * rhs);   // NaN-safe: keep the object unless provably far
-}
-
-// The same test in f32 on the f32 twin of the bound (DevBound32). Sources of error and where they go:
-//  * centre and apex rounded to f32: |w_f32 - w_true| <= b.ec + B.fep + 2^-24 |w| — added to the radius (Re);
-//  * f32 rounding of d2, wa (relative <= 3 * 2^-24 of |w|^2, |w|): Re carries 4e-6 * |w|_1, the cone inequality
-//    3e-6 * d2 on the "keep" side; axis / (cos, sin) unit only to ~2e-6: the 2e-5 factors;
-//  * r, k, cn are rounded up when the table is built (rtc_api.cpp, bound32_of).
-// Overflow and NaN fall through to "keep". Every inequality errs towards keeping the object; the exact f64 test
-// decides for what is kept, so results equal brute force bit for bit (tests/stress_parity.py).
-template <bool KEYED = false> DEVI bool bundle_touches32(const Bundle &B, const DevBound32 &b, float *key = nullptr) {
-#pragma clang fp contract(fast)
-    if constexpr (KEYED) *key = 0.f;
-    if (B.off) return true;
-    if (!(b.r < __builtin_inff())) return true;
-    const float wx = b.cx - B.fpx, wy = b.cy - B.fpy, wz = b.cz - B.fpz;
-    const float l1 = fabsf(wx) + fabsf(wy) + fabsf(wz);
-    const float epos = b.ec + B.fep;
-    const float Dub = (l1 + B.fspread) * 1.000001f + epos;            // >= distance centre -> ray origin
-    const float r_eff = b.r + b.r * (b.k * Dub * (b.cn + Dub)) * 1.00001f; // rounding inflation, see DevBound
-    const float Re = (r_eff + B.frho) * 1.00001f + 4e-6f * l1 + epos;
-    const float d2 = wx * wx + wy * wy + wz * wz;
-    if (!(d2 < 1e30f)) return true;
-    if (d2 <= Re * Re) return true;
-    if constexpr (KEYED) {
-        const float dist = __builtin_sqrtf(d2) * 0.99999f, rad = Re * 1.00001f;
-        *key = fmaxf(0.f, (dist - rad) * 0.99999f); // NaN / inf - inf -> 0: no bound
-    }
-    const float wa = wx * B.fax + wy * B.fay + wz * B.faz;
-    if (wa < -Re) return false;                            // wholly behind the apex plane
-    const float far = B.ftmax + Re;
-    if (d2 > far * far * 1.00001f) return false;           // beyond the reach of every ray (inf: never)
-    const float rhs = Re + (wa + fabsf(wa) * 2e-5f) * B.fsin;
-    if (rhs < 0.f) return false;
-    const float perp2 = d2 - wa * wa * 1.00002f;
-    return !(perp2 * (B.fcos * B.fcos) > rhs * rhs * 1.00001f + 3e-6f * d2); // NaN-safe: keep unless provably far
 }
 
 // Per-lane prefilter for INCOHERENT rays (reflection / refraction): can THIS lane's ray, for some
@@ -617,13 +563,7 @@ struct Tables {
     const uint32_t *__restrict__ orig_s;
     const DevBound *__restrict__ gbound;
     const DevIdEntry *__restrict__ idtab; // shapes in stable order of world_id (n1/n2 pass)
-    const DevBound32 *__restrict__ bound32, *__restrict__ bound32_s, *__restrict__ gbound32; // f32 twins (wave-level cull)
 };
-#if RTC_CULL_F32
-#define WAVE_CULL(KEYED, B, T64, T32, idx, key) bundle_touches32<KEYED>(B, (T32)[idx], key)
-#else
-#define WAVE_CULL(KEYED, B, T64, T32, idx, key) bundle_touches<KEYED>(B, (T64)[idx], key)
-#endif
 
 struct LdsView {
     double *m;      // [cap][12]
@@ -686,7 +626,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
             for (uint32_t sl = 0; sl < OS; ++sl) {
                 const uint32_t j = base + sl * 64u + lane;
                 bool cand = false;
-                if (base + sl * 64u < P.n && j < P.n) cand = WAVE_CULL(false, B, T.bound, T.bound32, j, nullptr);
+                if (base + sl * 64u < P.n && j < P.n) cand = bundle_touches(B, T.bound[j]);
                 masks[sl] = ballot(cand);
             }
 #pragma unroll
@@ -724,7 +664,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
                 if (k < cnt) {
                     DIAG_FILTER(ngrp);
                     const uint32_t j = gidx[k] * 64u + lane;
-                    if (j < P.n) cand = WAVE_CULL(ORDERED, B, T.bound_s, T.bound32_s, j, &okey[k]);
+                    if (j < P.n) cand = bundle_touches<ORDERED>(B, T.bound_s[j], &okey[k]);
                 }
                 masks[k] = ballot(cand);
             }
@@ -763,7 +703,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
                 bool gc = false;
                 float gkey = 0.f;
                 if (gbase + sl * 64u < P.ngroups && g < P.ngroups)
-                    gc = WAVE_CULL(ORDERED, B, T.gbound, T.gbound32, g, &gkey);
+                    gc = bundle_touches<ORDERED>(B, T.gbound[g], &gkey);
                 kb[sl] = gc ? __builtin_bit_cast(unsigned, gkey) : 0xffffffffu;
                 gm[sl] = ballot(gc);
             }
@@ -992,8 +932,7 @@ __global__ void __launch_bounds__(RTC_BLOCK_FOR(IS_CULL(SRC), REFL, REFR, PROBE)
 k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const uint32_t *__restrict__ t_kind,
         const DevShade *__restrict__ t_shade, const DevPrim *__restrict__ t_prim, const DevBound *__restrict__ t_bound,
         const DevIsect *__restrict__ t_isect_s, const uint32_t *__restrict__ t_kind_s, const DevBound *__restrict__ t_bound_s,
-        const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound, const DevIdEntry *__restrict__ t_idtab,
-        const DevBound32 *__restrict__ t_bound32, const DevBound32 *__restrict__ t_bound32_s, const DevBound32 *__restrict__ t_gbound32) {
+        const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound, const DevIdEntry *__restrict__ t_idtab) {
     constexpr uint32_t BLOCK = RTC_BLOCK_FOR(IS_CULL(SRC), REFL, REFR, PROBE), TILE_W = RTC_TILE_W_FOR(IS_CULL(SRC), REFL, REFR, PROBE);
     constexpr bool COMPACT = RTC_COMPACT_FOR(IS_CULL(SRC), REFL, REFR, PROBE); // K3: two waves, live rays merged between bounces
     extern __shared__ double lds_raw[];
@@ -1014,7 +953,6 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     T.isect = t_isect; T.kind = t_kind; T.shade = t_shade; T.prim = t_prim; T.bound = t_bound;
     T.isect_s = t_isect_s; T.kind_s = t_kind_s; T.bound_s = t_bound_s; T.orig_s = t_orig_s; T.gbound = t_gbound;
     T.idtab = t_idtab;
-    T.bound32 = t_bound32; T.bound32_s = t_bound32_s; T.gbound32 = t_gbound32;
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -1773,7 +1711,7 @@ static hipError_t launch_kernel(const RenderParams &P, dim3 grid, size_t lds_byt
     }
     // e0/e1 (may be NULL) receive the dispatch's own begin/end timestamps: no marker packets on the stream
     hipExtLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK_FOR(IS_CULL(SRC), REFL, REFR, PROBE)), lds_bytes, stream, e0, e1, 0, P, P.isect,
-                          P.kind, P.shade, P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound, P.idtab, P.bound32, P.bound32_s, P.gbound32);
+                          P.kind, P.shade, P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound, P.idtab);
     return hipGetLastError();
 }
 template <int SRC, bool REFL, bool REFR>
