@@ -23,6 +23,7 @@
 #include <stdexcept>
 #include <string>
 #include <utility>
+#include <cstring>
 #include <vector>
 
 #include "rtc.h"
@@ -210,12 +211,16 @@ class World { // shape.rs:633-795
     std::vector<Shape> shapes;
     uint32_t last_world_id = 0;
 
-    struct Uploaded { // flatten + upload for the duration of one call
+    // The flattened World resident in HBM. Camera::render(&World) takes the World by reference on every call
+    // (camera.rs:116,144); an animation loop calls it with the same World and a moving camera (lua.rs:34-41), so the
+    // upload is cached process-wide: re-flatten (materials may have been edited via get_material_mut), compare with what
+    // is resident, upload only when something changed.
+    struct Uploaded {
         rtc_world *w = nullptr;
         explicit Uploaded(const World &world) {
             std::vector<rtc_shape> flat;
             flat.reserve(world.shapes.size());
-            for (const Shape &s : world.shapes) { // re-flatten: materials may have been edited via get_material_mut
+            for (const Shape &s : world.shapes) {
                 rtc_shape f = s.flat;
                 f.material = s.material.flatten();
                 flat.push_back(f);
@@ -223,11 +228,35 @@ class World { // shape.rs:633-795
             rtc_light l;
             l.intensity[0] = world.light.intensity.red; l.intensity[1] = world.light.intensity.green; l.intensity[2] = world.light.intensity.blue;
             l.position[0] = world.light.position.x; l.position[1] = world.light.position.y; l.position[2] = world.light.position.z;
-            check(rtc_world_create(Device::get(), flat.data(), static_cast<uint32_t>(flat.size()), &l, &w), "World upload");
+            w = Resident::instance().get(std::move(flat), l);
         }
-        ~Uploaded() { rtc_world_destroy(w); }
         Uploaded(const Uploaded &) = delete;
         Uploaded &operator=(const Uploaded &) = delete;
+    };
+    class Resident { // the one World kept on the device between calls
+      public:
+        static Resident &instance() {
+            static Resident r;
+            return r;
+        }
+        rtc_world *get(std::vector<rtc_shape> &&flat, const rtc_light &l) {
+            const bool same = w_ != nullptr && flat.size() == flat_.size() && std::memcmp(&l, &light_, sizeof l) == 0 &&
+                              (flat.empty() || std::memcmp(flat.data(), flat_.data(), flat.size() * sizeof(rtc_shape)) == 0);
+            if (!same) {
+                if (w_) rtc_world_destroy(w_);
+                w_ = nullptr;
+                check(rtc_world_create(Device::get(), flat.data(), static_cast<uint32_t>(flat.size()), &l, &w_), "World upload");
+                flat_ = std::move(flat);
+                light_ = l;
+            }
+            return w_;
+        }
+      private:
+        Resident() { (void)Device::get(); } // the context outlives this cache (constructed first, destroyed last)
+        ~Resident() { if (w_) rtc_world_destroy(w_); }
+        rtc_world *w_ = nullptr;
+        std::vector<rtc_shape> flat_;
+        rtc_light light_{};
     };
   private:
     bool dirty_ = false;

@@ -119,8 +119,34 @@ static void test_panics() {
     EXPECT(threw); // material.rs:331
 }
 
+// The façade keeps ONE flattened World resident on the device between calls (ch1::World::Resident): an unchanged
+// World must not be re-uploaded, an edited one must be, and antialiasing_samples = 0 takes the 4-sub-sample branch
+// (camera.rs:96-99: only the value 1 is the one-ray branch).
+static void test_resident_world_and_samples() {
+    World world = World::default_();
+    Camera cam = Camera::new_with_transform(24, 16, M_PI / 2.0,
+        Matrix::make_view_transform(Point::new_(0., 0., -5.), Point::new_(0., 0., 0.), Vector::new_(0., 1., 0.)));
+    const Canvas a = cam.render_async(world);
+    rtc_world *first = World::Resident::instance().get({}, rtc_light{}); // forces a different (empty) World in ...
+    (void)first;
+    const Canvas b = cam.render_async(world);                              // ... so this call uploads again
+    EXPECT(a.pixels == b.pixels);
+    const Canvas c = cam.render_async(world);                              // unchanged: served from the resident copy
+    EXPECT(a.pixels == c.pixels);
+    world.get_shape_mut(0).material.ambient = 0.9;                         // an edit must be seen
+    const Canvas d = cam.render_async(world);
+    EXPECT(!(a.pixels == d.pixels));
+    Camera aa = cam;
+    aa.set_samples(0);
+    const Canvas e = aa.render_async(world);
+    aa.set_samples(4);
+    const Canvas f = aa.render_async(world);
+    EXPECT(e.pixels == f.pixels && !(e.pixels == d.pixels));
+}
+
 int main(int argc, char **argv) {
     try {
+        test_resident_world_and_samples();
         test_render1();
         test_async1();
         test_color_at();
