@@ -1,10 +1,8 @@
-# The other single-GPU configurations of DESIGN.md's table (same build as the headline run).
+# The BASELINE.json configurations on one GPU (same build as the headline run): bash tools/other_configs.sh
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-run() { tag=$1; shift; timeout -k 10 300 python bench.py --no-cpu-baseline "$@" > gpurun_out/cfg_$tag.log 2>&1; grep -a '^{' gpurun_out/cfg_$tag.log | python3 -c "
-import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print('$tag', d['ms_per_step'], 'ms/frame', d['value'], 'Mrays/s', c['rays_per_frame_primary_shadow'], c['rays_per_frame_other'], 'kernel', d['roofline']['kernel_ms_avg'])"; }
-run c2 --spheres 3 --steps 200 --warmup 20 &&
-run c3 --spheres 10000 --no-plane --steps 100 --warmup 10 &&
-run c4 --spheres 100 --width 4096 --height 4096 --reflective --steps 30 --warmup 5 &&
-run c5 --spheres 1000 --width 8192 --height 8192 --steps 20 --warmup 3 &&
-run ns --steps 400 --warmup 40
+for w in c2 c3 c4 c5 ns; do
+  timeout -k 10 300 python bench.py --workload $w --steps 64 --warmup 8 --no-cpu-baseline > gpurun_out/cfg_$w.log 2>&1
+  grep -a '^{' gpurun_out/cfg_$w.log | python3 -c "
+import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print('$w', d['ms_per_step'], 'ms/frame', d['value'], 'Mrays/s', c['rays_per_frame_primary_shadow'], c['rays_per_frame_other'], 'kernel/frame', d['roofline']['kernel_ms_per_frame'], 'single_view', d['single_view']['ms_per_step'])"
+done
