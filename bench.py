@@ -449,28 +449,71 @@ def measure_dropin(rtc, np, torch, dev_index, world, cam, grouped, group, gworld
         d.close()
         c.close()
     else:
-        # every rank maps ONE shared-memory canvas and DMAs its own bands into it over its own PCIe link
+        # every rank maps ONE shared-memory canvas and DMAs its own bands into it over its own PCIe link. Every barrier below
+        # is executed by every rank whatever happens locally (a rank that fails must not leave the others waiting).
         path = f"/dev/shm/rtc_bench_canvas_{os.environ.get('MASTER_PORT', '0')}"
-        if rank == 0:
-            with open(path, "wb") as f:
-                f.truncate(nbytes)
+        err = None
+        shared, registered = None, False
+        try:
+            if rank == 0:
+                with open(path, "wb") as f:
+                    f.truncate(nbytes)
+        except Exception as e:   # noqa: BLE001
+            err = f"create: {e}"
         barrier()
-        shared = np.memmap(path, dtype=np.float64, mode="r+", shape=(H, W, 3))
-        rtc.host_register(shared)
-        out["rtc_group_render_host_ms"] = per_frame(lambda: gworld.render_host(cam, shared))
-        ok = True
-        if rank == 0:
-            c = rtc.Context(dev_index)
-            ok = bool(np.array_equal(np.asarray(shared), c.upload(world).render(cam)))
-            c.close()
-        out["shared_canvas_vs_single_gpu_render"] = "ok" if ok else "MISMATCH"
+        try:
+            shared = np.memmap(path, dtype=np.float64, mode="r+", shape=(H, W, 3))
+            try:
+                rtc.host_register(shared)
+                registered = True
+            except Exception:    # noqa: BLE001 - an unregistered mapping still works (bounce buffers)
+                registered = False
+        except Exception as e:   # noqa: BLE001
+            err = err or f"map: {e}"
+
+        def frame():
+            if shared is not None:
+                gworld.render_host(cam, shared)
+        try:
+            frame()
+        except Exception as e:   # noqa: BLE001
+            err = err or f"render_host: {e}"
+            shared = None
+        barrier()
+        t = time.perf_counter()
+        try:
+            for _ in range(frames):
+                frame()
+        except Exception as e:   # noqa: BLE001
+            err = err or f"render_host: {e}"
+        barrier()
+        out["rtc_group_render_host_ms"] = round((time.perf_counter() - t) / frames * 1e3, 4)
+        out["host_canvas_registered"] = registered
+        ok = None
+        if rank == 0 and shared is not None and err is None:
+            try:
+                c = rtc.Context(dev_index)
+                ok = bool(np.array_equal(np.asarray(shared), c.upload(world).render(cam)))
+                c.close()
+            except Exception as e:   # noqa: BLE001
+                err = f"check: {e}"
+        out["shared_canvas_vs_single_gpu_render"] = "ok" if ok else ("MISMATCH" if ok is False else "not checked")
+        if err:
+            out["error"] = err
         out["note"] = (f"ms per frame for Camera::render_async into ONE host canvas (shared memory, page-locked in every process): each of the {N} "
                        "GPUs DMAs its bands straight to their rows over its own PCIe link (rtc_group_render_host); no gather")
-        rtc.host_unregister(shared)
+        try:
+            if registered:
+                rtc.host_unregister(shared)
+        except Exception:        # noqa: BLE001
+            pass
         del shared
         barrier()
         if rank == 0:
-            os.unlink(path)
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
     return out
 
 
