@@ -241,6 +241,7 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
         const int v = std::atoi(e);
         if (v >= 0 && v <= 4) ctx->force_src = v;
     }
+    if (const char *e = std::getenv("RTC_BINNING")) ctx->binning = std::atoi(e) != 0;
     if (const char *e = std::getenv("RTC_TILE_CAP")) {
         const int v = std::atoi(e);
         if (v >= 16 && v <= 1024) ctx->tile_cap = (uint32_t)v;
@@ -428,7 +429,10 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
               hipMalloc(&w->d_bound_s, sizeof(DevBound) * na) == hipSuccess &&
               hipMalloc(&w->d_orig_s, sizeof(uint32_t) * na) == hipSuccess &&
               hipMalloc(&w->d_gbound, sizeof(DevBound) * gbound.size()) == hipSuccess &&
-              hipMalloc(&w->d_idtab, sizeof(DevIdEntry) * na) == hipSuccess;
+              hipMalloc(&w->d_idtab, sizeof(DevIdEntry) * na) == hipSuccess &&
+              hipMalloc(&w->d_bin_global, sizeof(uint32_t) * RTC_MAX_VIEWS * (RTC_BIN_WIDE_CAP + 1u)) == hipSuccess;
+    for (uint32_t i = 0; i < n; ++i)
+        if (!std::isfinite(bound_s[i].r)) w->n_unb = i + 1u; // unbounded objects sort first (key 0)
     ok = ok && hipMemcpy(w->d_isect, isect.data(), sizeof(DevIsect) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_kind, kind.data(), sizeof(uint32_t) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_shade, shade.data(), sizeof(DevShade) * na, hipMemcpyHostToDevice) == hipSuccess &&
@@ -465,6 +469,11 @@ void rtc_world_destroy(rtc_world *w) {
     if (w->d_orig_s) (void)hipFree(w->d_orig_s);
     if (w->d_gbound) (void)hipFree(w->d_gbound);
     if (w->d_idtab) (void)hipFree(w->d_idtab);
+    if (w->d_tile_bundles) (void)hipFree(w->d_tile_bundles);
+    if (w->d_macro_bundles) (void)hipFree(w->d_macro_bundles);
+    if (w->d_tile_cnt) (void)hipFree(w->d_tile_cnt);
+    if (w->d_tile_list) (void)hipFree(w->d_tile_list);
+    if (w->d_bin_global) (void)hipFree(w->d_bin_global);
     delete w;
 }
 
@@ -502,9 +511,42 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
         // Camera::resample traces `antialiasing_samples` more rays (camera.rs:87); u8 in the reference
         P.resample_n = (flags & RTC_FLAG_AA_RESAMPLE) ? (cam->samples & 0xffu) : 0u;
     }
-    // per-render camera tables of two-level worlds: every primary bundle of view v starts at that camera's origin
-    // (transform_point(view_inv, (0,0,0)) camera.rs:72, the kernel's own expression), so the apex-dependent half of the
-    // wave-level bound test is evaluated once per object here instead of once per (wave, object)
+    // binned primary pass (two-level worlds, one ray per pixel, tile rows aligned with the image's): three small kernels put
+    // every object on the list of each 8x8 tile its bounding sphere can touch (same conservative predicate as the wave-level
+    // cull), so the render kernel's primary pass runs exact tests on a short list instead of walking the groups
+    if (src == SRC_CULL2 && ctx->binning && P.samples == 1u && (y0 % 8u) == 0u && w->n != 0u && w->d_bin_global) {
+        const uint32_t tiles_x = (cam->hsize + 7u) / 8u, tiles_y = (cam->vsize + 7u) / 8u;
+        const uint32_t macros_x = (tiles_x + 7u) / 8u, macros_y = (tiles_y + 7u) / 8u;
+        // macro tiles and super tiles (8x8 macro tiles) share one buffer
+        const size_t tiles = (size_t)tiles_x * tiles_y * nviews,
+                     macros = ((size_t)macros_x * macros_y + (size_t)((macros_x + 7u) / 8u) * ((macros_y + 7u) / 8u)) * nviews;
+        if (w->bin_tiles_cap < tiles) {
+            if (w->d_tile_bundles) (void)hipFree(w->d_tile_bundles);
+            if (w->d_tile_cnt) (void)hipFree(w->d_tile_cnt);
+            if (w->d_tile_list) (void)hipFree(w->d_tile_list);
+            w->d_tile_bundles = nullptr; w->d_tile_cnt = nullptr; w->d_tile_list = nullptr;
+            w->bin_tiles_cap = 0;
+            HIP_TRY(hipMalloc(&w->d_tile_bundles, sizeof(DevTileBundle) * tiles));
+            HIP_TRY(hipMalloc(&w->d_tile_cnt, sizeof(uint32_t) * tiles));
+            HIP_TRY(hipMalloc(&w->d_tile_list, sizeof(uint32_t) * tiles * RTC_TILE_LIST_CAP));
+            w->bin_tiles_cap = tiles;
+        }
+        if (w->bin_macros_cap < macros) {
+            if (w->d_macro_bundles) (void)hipFree(w->d_macro_bundles);
+            w->d_macro_bundles = nullptr;
+            w->bin_macros_cap = 0;
+            HIP_TRY(hipMalloc(&w->d_macro_bundles, sizeof(DevTileBundle) * macros));
+            w->bin_macros_cap = macros;
+        }
+        HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound, w->d_tile_bundles, w->d_macro_bundles,
+                                   w->d_tile_cnt, w->d_tile_list, w->d_bin_global, ctx->stream));
+        P.tile_cnt = w->d_tile_cnt;
+        P.tile_list = w->d_tile_list;
+        P.tiles_x = tiles_x;
+        P.tiles_y = tiles_y;
+        P.bin_wide = w->d_bin_global;
+        P.n_unb = w->n_unb;
+    }
     // per-render prologue table of the brute-force variants (the culled kernels do not use it)
     if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.views[0].vinv, ctx->stream));
     // start/stop events cost ~9 us of host time and ~5 us of GPU time per launch (measured): callers

@@ -30,6 +30,7 @@ struct rtc_context {
     size_t canvas_bytes = 0;
     int force_src = -1;   // RTC_SRC env override (experiments)
     uint32_t tile_cap = 512;
+    bool binning = true;  // RTC_BINNING=0: two-level worlds walk the groups for primary rays too (A/B)
 };
 
 struct rtc_world {
@@ -47,12 +48,21 @@ struct rtc_world {
     uint32_t *d_orig_s = nullptr;
     DevBound *d_gbound = nullptr;
     DevIdEntry *d_idtab = nullptr;
+    // binned primary pass (two-level worlds): per-render scratch, grow-only (rtc_render_* take the World as const: mutable)
+    mutable DevTileBundle *d_tile_bundles = nullptr, *d_macro_bundles = nullptr;
+    mutable uint32_t *d_tile_cnt = nullptr, *d_tile_list = nullptr;
+    uint32_t *d_bin_global = nullptr; // [RTC_MAX_VIEWS][1 + RTC_BIN_WIDE_CAP]: deferred wide objects per view
+    uint32_t n_unb = 0;               // unbounded objects: the first n_unb entries of the Morton-sorted tables
+    mutable size_t bin_tiles_cap = 0, bin_macros_cap = 0; // capacity in (view, tile) / (view, macro tile) entries
     uint32_t ngroups = 0;
     rtc_light light{};
     bool any_refl = false, any_refr = false;
 };
 
 
+extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound,
+                                         DevTileBundle *tile_bundles, DevTileBundle *macro_bundles, uint32_t *cnt, uint32_t *list,
+                                         uint32_t *wide, hipStream_t stream);
 extern "C" hipError_t rtc_launch_undeal(const void *staging, void *canvas, uint32_t nranks, uint32_t nframes, uint32_t H,
                                         uint32_t rows_max, size_t row_bytes, hipStream_t stream);
 

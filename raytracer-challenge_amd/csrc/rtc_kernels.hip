@@ -518,6 +518,22 @@ template <bool KEYED = false> DEVI bool bundle_touches(const Bundle &B, const De
     return !(perp2 * (B.cosT * B.cosT) > rhs * rhs);   // NaN-safe: keep the object unless provably far
 }
 
+// The KEY of bundle_touches<true> on its own: a lower bound of the distance from `apex` to the bound's inflated sphere
+// (0 when the apex may be inside or nothing can be said). Rays that start at the apex with unit directions meet the object
+// only at t >= key.
+DEVI float bound_key(V3 apex, const DevBound &b) {
+#pragma clang fp contract(fast)
+    if (!(b.r < __builtin_inf())) return 0.f;
+    const double wx = b.cx - apex.x, wy = b.cy - apex.y, wz = b.cz - apex.z;
+    const double l1 = fabs(wx) + fabs(wy) + fabs(wz);
+    const double r_eff = b.r + b.r * (b.k * l1 * (b.cn + l1));
+    const double Re = r_eff * 1.00001 + 1e-6 * l1 + 1e-12;
+    const double d2 = wx * wx + wy * wy + wz * wz;
+    if (d2 <= Re * Re) return 0.f;
+    const float dist = __builtin_sqrtf((float)d2) * 0.999999f, rad = (float)Re * 1.000001f;
+    return fmaxf(0.f, (dist - rad) * 0.999999f); // NaN / inf - inf -> 0: no bound
+}
+
 // Per-lane prefilter for INCOHERENT rays (reflection / refraction): can THIS lane's ray, for some
 // t >= 0, touch the object's bounding sphere? false => the exact test would find no entry with
 // t >= 0 for this lane. ~22 f64 instructions against 54+ for the exact test; the exact test is
@@ -1123,8 +1139,28 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             int hidx = -1, hroot = 0;
             Bundle B{}; // every field defined: an undefined field turns into a value carried around the pass loop
             B.off = true;
+            // binned primary pass (two-level worlds): this wave's 8x8 tile has a list of the objects its primary rays can touch
+            bool binned = false;
+            uint32_t bin_cnt = 0;
+            const uint32_t *bin_list = nullptr;
+            if constexpr (SRC == SRC_CULL2 && !PROBE) {
+                if (shared_origin && first) {
+                    const auto &Pt = KP(P_arg);
+                    if (Pt.tile_cnt != nullptr) {
+                        const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave); // wave-uniform by construction
+                        const uint32_t itx = (tbid % Pt.grid_x) * (TILE_W / 8u) + wv, ity = (Pt.y0 >> 3) + (tbid / Pt.grid_x) * Pt.band_stride;
+                        if (itx < Pt.tiles_x && ity < Pt.tiles_y) {
+                            const size_t tile = (size_t)(view * Pt.tiles_y + ity) * Pt.tiles_x + itx;
+                            bin_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)Pt.tile_cnt[tile]);
+                            bin_list = Pt.tile_list + tile * RTC_TILE_LIST_CAP;
+                            // an overflowing list (the tile's, or the view's list of deferred wide objects) is incomplete: walk instead
+                            binned = bin_cnt <= RTC_TILE_LIST_CAP && Pt.bin_wide[(size_t)view * (RTC_BIN_WIDE_CAP + 1u)] <= RTC_BIN_WIDE_CAP;
+                        }
+                    }
+                }
+            }
             if constexpr (IS_CULL(SRC)) {
-                if (ballot(tracing) != 0ull) {
+                if (ballot(tracing) != 0ull && !binned) {
                     if (shared_origin && first) B = make_bundle<true, false>(tracing, cam_origin, ro, rd, 0.);
                     else B = make_bundle<false, false>(tracing, cam_origin, ro, rd, 0.);
 #ifdef RTC_NO_SECONDARY_CULL
@@ -1153,6 +1189,32 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     return true;
                 }, ro, rd, NoSkip{}, DIAG_PTR(6), DIAG_PTR(8), DIAG_PTR(10));
 #endif
+            } else if (SRC == SRC_CULL2 && !PROBE && shared_origin && first && binned) {
+                // binned primary pass: the unbounded objects, then the tile's own list (k_bin_objects / k_bin_wide) — together
+                // every object this tile's rays can touch
+                const auto &Pb = KP(P_arg);
+                for (uint32_t k = 0; k < Pb.n_unb; ++k) {
+                    DIAG(2, 1u);
+                    if (tracing) closest_world(T.kind_s[k], T.isect_s[k].m, ro, rd, (int)T.orig_s[k], best, hidx, hroot);
+                }
+                // the tile's list, nearest first: lane e holds entry e and the lower bound of the distance from the camera to
+                // its (inflated) bounding sphere — every intersection of that object has t >= key for these unit-direction
+                // rays — and the walk stops at the first key no lane can use any more (as the ordered group walk does)
+                uint32_t my_j = 0u;
+                float my_key = 0.f;
+                if (lane < bin_cnt) {
+                    my_j = bin_list[lane];
+                    my_key = bound_key(cam_origin, T.bound[my_j]);
+                }
+                unsigned long long lmask = bin_cnt >= 64u ? ~0ull : ((1ull << bin_cnt) - 1ull);
+                while (lmask) {
+                    float kmin;
+                    const int sel = take_min_key(lmask, my_key, kmin);
+                    if (ballot(tracing && !(best < (double)kmin)) == 0ull) break;
+                    const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)my_j, sel);
+                    DIAG(2, 1u);
+                    if (tracing) closest_world(T.kind[j], T.isect[j].m, ro, rd, (int)j, best, hidx, hroot);
+                }
             } else if (SRC == SRC_CULL2 && !PROBE && shared_origin && first) {
                 // primary rays of a large world: start at the apex, unit direction -> ordered walk with early stop
                 for_each_object<SRC, false>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
@@ -1663,6 +1725,210 @@ __global__ void k_arith(uint32_t op, const double *a, const double *b, uint32_t 
     default: r = fmod(a[i], 2.0); break;
     }
     out[i] = r;
+}
+
+// ---- binned primary pass: per-view tile lists (DevTileBundle, rtc_device.h) ---------------------------------------
+// Primary ray of pixel (px, py) of one camera: Camera::ray_for_pixel_offset(x, 0.5, y, 0.5) camera.rs:64-76, the
+// expression k_trace evaluates.
+DEVI V3 primary_dir(const DevCamera &C, V3 cam_origin, uint32_t px, uint32_t py) {
+    const double xoffset = ((double)px + 0.5) * C.pixel_size;
+    const double yoffset = ((double)py + 0.5) * C.pixel_size;
+    const double world_x = C.half_width - xoffset;
+    const double world_y = C.half_height - yoffset;
+    const V3 pixel = xpoint(C.vinv, mk(world_x, world_y, -1.));
+    return vnormalize(vsub(pixel, cam_origin));
+}
+
+struct BinParams {
+    DevCamera views[RTC_MAX_VIEWS];
+    uint32_t nviews, W, H, n;
+    uint32_t tiles_x, tiles_y, macros_x, macros_y, supers_x, supers_y; // 8x8 pixels, 8x8 tiles, 8x8 macro tiles
+};
+
+DEVI Bundle bundle_of(const DevTileBundle &t, V3 apex) { // a stored cone as the Bundle bundle_touches takes (rho 0, no reach)
+    Bundle B{};
+    B.px = apex.x; B.py = apex.y; B.pz = apex.z;
+    B.ax = (double)t.ax; B.ay = (double)t.ay; B.az = (double)t.az;
+    B.cosT = (double)t.cosT; B.sinT = (double)t.sinT;
+    B.rho = 0.; B.tmax = __builtin_inf(); B.spread = 0.;
+    B.off = t.off != 0u;
+    return B;
+}
+
+// f32 unit direction as make_bundle takes it from a lane's f64 direction
+DEVI bool dir_f32(V3 d, float &fx, float &fy, float &fz) {
+    const float x = (float)d.x, y = (float)d.y, z = (float)d.z;
+    const float l2 = x * x + y * y + z * z;
+    const float il = __builtin_amdgcn_rsqf(l2);
+    fx = x * il; fy = y * il; fz = z * il;
+    return finite3(d) && l2 > 1e-30f && l2 < 1e30f;
+}
+
+// One THREAD per (view, cell) for all three levels at once — tiles of 8x8 pixels, macro tiles of 64x64, super tiles of
+// 512x512: the cone of the cell's primary rays with make_bundle's arithmetic and margins, from five rays instead of all:
+// the axis ray (a pixel near the cell's centre) and the four corner pixels. The angle between a ray through the image
+// plane and a fixed axis is a quasi-convex function of the pixel position (its sub-level sets are the interiors of conic
+// sections), so over the cell's rectangle of pixel centres it peaks at a corner; the reference arithmetic's rounding
+// (1e-16) and the f32 conversion (6e-8) sit far inside make_bundle's margins (sinT * 1.001 + 4e-6). All pixels inside the
+// image count: a superset of the lanes Camera::render traces. Tile threads also clear their tile's list counter.
+__global__ void __launch_bounds__(256) k_cell_bundles(const BinParams Q, DevTileBundle *__restrict__ tiles_out,
+                                                      DevTileBundle *__restrict__ macros_out, DevTileBundle *__restrict__ supers_out,
+                                                      uint32_t *__restrict__ cnt, uint32_t *__restrict__ wide) {
+#pragma clang fp contract(fast)
+    const uint32_t nt = Q.nviews * Q.tiles_x * Q.tiles_y, nm = Q.nviews * Q.macros_x * Q.macros_y, ns = Q.nviews * Q.supers_x * Q.supers_y;
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < Q.nviews * (RTC_BIN_WIDE_CAP + 1u)) wide[i] = 0u; // the views' lists of deferred (wide) objects: count + entries
+    uint32_t gx, gy, cell;
+    DevTileBundle *out;
+    if (i < nt) { gx = Q.tiles_x; gy = Q.tiles_y; cell = 8u; out = tiles_out; cnt[i] = 0u; }
+    else if ((i -= nt) < nm) { gx = Q.macros_x; gy = Q.macros_y; cell = 64u; out = macros_out; }
+    else if ((i -= nm) < ns) { gx = Q.supers_x; gy = Q.supers_y; cell = 512u; out = supers_out; }
+    else return;
+    const uint32_t view = i / (gx * gy), t = i % (gx * gy);
+    const uint32_t x0 = (t % gx) * cell, y0 = (t / gx) * cell;
+    const uint32_t x1 = min(x0 + cell - 1u, Q.W - 1u), y1 = min(y0 + cell - 1u, Q.H - 1u);
+    const DevCamera &C = Q.views[view];
+    const V3 o = xpoint(C.vinv, mk(0., 0., 0.));
+    float ax, ay, az;
+    bool good = finite3(o) && dir_f32(primary_dir(C, o, min(x0 + cell / 2u - 1u, x1), min(y0 + cell / 2u - 1u, y1)), ax, ay, az);
+    float q2max = 0.f;
+    bool narrow = true;
+    const uint32_t cx[4] = {x0, x1, x0, x1}, cy[4] = {y0, y0, y1, y1};
+    for (int k = 0; k < 4; ++k) {
+        float fx, fy, fz;
+        good = dir_f32(primary_dir(C, o, cx[k], cy[k]), fx, fy, fz) && good;
+        const float dotv = ax * fx + ay * fy + az * fz;
+        const float ux = ay * fz - az * fy, uy = az * fx - ax * fz, uz = ax * fy - ay * fx;
+        q2max = fmaxf(q2max, ux * ux + uy * uy + uz * uz);
+        narrow = narrow && dotv > 0.7f;
+    }
+    DevTileBundle r;
+    r.ax = ax; r.ay = ay; r.az = az;
+    r.sinT = __builtin_sqrtf(q2max) * 1.001f + 4e-6f;
+    r.cosT = __builtin_sqrtf(fmaxf(0.f, 1.f - r.sinT * r.sinT));
+    r.off = (good && narrow && r.sinT < 0.98f) ? 0u : 1u; // wide or odd cells: every object is a candidate
+    out[i] = r;
+}
+
+// Level 3 of the binning: the tiles of macro tile (mxs, mys), one per lane.
+DEVI void bin_tiles_of_macro(const BinParams &Q, uint32_t view, uint32_t mxs, uint32_t mys, uint32_t lane, V3 o, const DevBound &b, uint32_t j,
+                             const DevTileBundle *__restrict__ tb, uint32_t *__restrict__ cnt, uint32_t *__restrict__ list) {
+    const uint32_t tx = mxs * 8u + (lane & 7u), ty = mys * 8u + (lane >> 3);
+    if (tx < Q.tiles_x && ty < Q.tiles_y) {
+        const size_t tile = (size_t)(view * Q.tiles_y + ty) * Q.tiles_x + tx;
+        if (bundle_touches(bundle_of(tb[tile], o), b)) {
+            const uint32_t slot = atomicAdd(cnt + tile, 1u);
+            if (slot < RTC_TILE_LIST_CAP) list[tile * RTC_TILE_LIST_CAP + slot] = j;
+        }
+    }
+}
+
+// One wave per (view, object): the object goes on the list of every tile whose cone its bounding sphere can touch
+// (bundle_touches, the wave-level cull's predicate). Three levels, 64 cells per step, one per lane: super tiles, the macro
+// tiles of touched super tiles, the tiles of touched macro tiles. Pass 1 counts the macro tiles touched; an object that
+// touches more than RTC_BIN_WIDE of them is DEFERRED to k_bin_wide, which spreads it over one wave per super tile (one
+// wave appending to thousands of tiles would run for milliseconds).
+__global__ void __launch_bounds__(64) k_bin_objects(const BinParams Q, const DevBound *__restrict__ bound, const DevTileBundle *__restrict__ tb,
+                                                     const DevTileBundle *__restrict__ mb, const DevTileBundle *__restrict__ sb,
+                                                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ list, uint32_t *__restrict__ wide) {
+    const uint32_t view = blockIdx.x / Q.n, j = blockIdx.x % Q.n, lane = threadIdx.x;
+    const DevBound b = bound[j];
+    if (!(b.r < __builtin_inf())) return; // unbounded: every tile tests it anyway (the sorted tables' first n_unb entries)
+    const DevCamera &C = Q.views[view];
+    V3 o = xpoint(C.vinv, mk(0., 0., 0.));
+    o = mk(uniform_f64(o.x), uniform_f64(o.y), uniform_f64(o.z));
+    const uint32_t supers = Q.supers_x * Q.supers_y, macros = Q.macros_x * Q.macros_y;
+    for (int pass = 0; pass < 2; ++pass) {
+        uint32_t touched = 0;
+        for (uint32_t sbase = 0; sbase < supers; sbase += 64u) {
+            const uint32_t sidx = sbase + lane;
+            bool ts = false;
+            if (sidx < supers) ts = bundle_touches(bundle_of(sb[(size_t)view * supers + sidx], o), b);
+            unsigned long long smask = ballot(ts);
+            while (smask) {
+                const uint32_t ssel = sbase + (uint32_t)__builtin_ctzll(smask);
+                smask &= smask - 1ull;
+                const uint32_t mx = (ssel % Q.supers_x) * 8u + (lane & 7u), my = (ssel / Q.supers_x) * 8u + (lane >> 3);
+                bool tm = false;
+                if (mx < Q.macros_x && my < Q.macros_y) tm = bundle_touches(bundle_of(mb[(size_t)view * macros + my * Q.macros_x + mx], o), b);
+                unsigned long long mmask = ballot(tm);
+                touched += popc64(mmask);
+                if (pass == 0) {
+                    if (touched > RTC_BIN_WIDE) {
+                        if (lane == 0) {
+                            uint32_t *wl = wide + (size_t)view * (RTC_BIN_WIDE_CAP + 1u);
+                            const uint32_t slot = atomicAdd(wl, 1u);
+                            if (slot < RTC_BIN_WIDE_CAP) wl[1u + slot] = j;
+                        }
+                        return;
+                    }
+                    continue;
+                }
+                while (mmask) {
+                    const uint32_t l = (uint32_t)__builtin_ctzll(mmask);
+                    mmask &= mmask - 1ull;
+                    bin_tiles_of_macro(Q, view, (ssel % Q.supers_x) * 8u + (l & 7u), (ssel / Q.supers_x) * 8u + (l >> 3), lane, o, b, j, tb, cnt, list);
+                }
+            }
+        }
+    }
+}
+
+// Deferred (wide) objects: RTC_BIN_WIDE_WORKERS waves per (view, super tile); worker k takes the view's deferred objects
+// k, k + WORKERS, ... and bins each one's tiles inside that super tile.
+#define RTC_BIN_WIDE_WORKERS 32u
+__global__ void __launch_bounds__(64) k_bin_wide(const BinParams Q, const DevBound *__restrict__ bound, const DevTileBundle *__restrict__ tb,
+                                                  const DevTileBundle *__restrict__ mb, const DevTileBundle *__restrict__ sb,
+                                                  uint32_t *__restrict__ cnt, uint32_t *__restrict__ list, const uint32_t *__restrict__ wide) {
+    const uint32_t supers = Q.supers_x * Q.supers_y, macros = Q.macros_x * Q.macros_y;
+    const uint32_t ssel = blockIdx.x % supers, worker = (blockIdx.x / supers) % RTC_BIN_WIDE_WORKERS, view = blockIdx.x / (supers * RTC_BIN_WIDE_WORKERS);
+    const uint32_t lane = threadIdx.x;
+    const uint32_t *wl = wide + (size_t)view * (RTC_BIN_WIDE_CAP + 1u);
+    const uint32_t ndef = min(wl[0], RTC_BIN_WIDE_CAP); // wl[0] > RTC_BIN_WIDE_CAP: the list overflowed, this view's tiles walk (k_trace checks)
+    if (worker >= ndef) return;
+    const DevCamera &C = Q.views[view];
+    V3 o = xpoint(C.vinv, mk(0., 0., 0.));
+    o = mk(uniform_f64(o.x), uniform_f64(o.y), uniform_f64(o.z));
+    const DevTileBundle sbun = sb[(size_t)view * supers + ssel];
+    const uint32_t mx = (ssel % Q.supers_x) * 8u + (lane & 7u), my = (ssel / Q.supers_x) * 8u + (lane >> 3);
+    const bool mvalid = mx < Q.macros_x && my < Q.macros_y;
+    DevTileBundle mbun{0.f, 0.f, 1.f, 1.f, 0.f, 0u};
+    if (mvalid) mbun = mb[(size_t)view * macros + my * Q.macros_x + mx];
+    for (uint32_t d = worker; d < ndef; d += RTC_BIN_WIDE_WORKERS) {
+        const uint32_t j = wl[1u + d];
+        const DevBound b = bound[j];
+        if (!bundle_touches(bundle_of(sbun, o), b)) continue;
+        unsigned long long mmask = ballot(mvalid && bundle_touches(bundle_of(mbun, o), b));
+        while (mmask) {
+            const uint32_t l = (uint32_t)__builtin_ctzll(mmask);
+            mmask &= mmask - 1ull;
+            bin_tiles_of_macro(Q, view, (ssel % Q.supers_x) * 8u + (l & 7u), (ssel / Q.supers_x) * 8u + (l >> 3), lane, o, b, j, tb, cnt, list);
+        }
+    }
+}
+
+extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound,
+                                         DevTileBundle *tile_bundles, DevTileBundle *macro_bundles, uint32_t *cnt, uint32_t *list,
+                                         uint32_t *wide, hipStream_t stream) {
+    BinParams Q;
+    for (uint32_t v = 0; v < nviews; ++v) Q.views[v] = views[v];
+    for (uint32_t v = nviews; v < RTC_MAX_VIEWS; ++v) Q.views[v] = views[0];
+    Q.nviews = nviews; Q.W = W; Q.H = H; Q.n = n;
+    Q.tiles_x = (W + 7u) / 8u; Q.tiles_y = (H + 7u) / 8u;
+    Q.macros_x = (Q.tiles_x + 7u) / 8u; Q.macros_y = (Q.tiles_y + 7u) / 8u;
+    Q.supers_x = (Q.macros_x + 7u) / 8u; Q.supers_y = (Q.macros_y + 7u) / 8u;
+    const uint32_t tiles = Q.tiles_x * Q.tiles_y, macros = Q.macros_x * Q.macros_y, supers = Q.supers_x * Q.supers_y;
+    DevTileBundle *super_bundles = macro_bundles + (size_t)nviews * macros; // the caller sized macro_bundles for both levels
+    const uint32_t cells = nviews * (tiles + macros + supers), need = nviews * (RTC_BIN_WIDE_CAP + 1u);
+    hipLaunchKernelGGL(k_cell_bundles, dim3(((cells > need ? cells : need) + 255u) / 256u), dim3(256), 0, stream, Q, tile_bundles, macro_bundles,
+                       super_bundles, cnt, wide);
+    if (n) {
+        hipLaunchKernelGGL(k_bin_objects, dim3(nviews * n), dim3(64), 0, stream, Q, bound, (const DevTileBundle *)tile_bundles,
+                           (const DevTileBundle *)macro_bundles, (const DevTileBundle *)super_bundles, cnt, list, wide);
+        hipLaunchKernelGGL(k_bin_wide, dim3(nviews * RTC_BIN_WIDE_WORKERS * supers), dim3(64), 0, stream, Q, bound, (const DevTileBundle *)tile_bundles,
+                           (const DevTileBundle *)macro_bundles, (const DevTileBundle *)super_bundles, cnt, list, (const uint32_t *)wide);
+    }
+    return hipGetLastError();
 }
 
 // Un-deal (rtc_group_render, member 0): the gather leaves N chunks, chunk p = member p's packed bands of
