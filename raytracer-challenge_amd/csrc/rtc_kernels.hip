@@ -1139,11 +1139,11 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             int hidx = -1, hroot = 0;
             Bundle B{}; // every field defined: an undefined field turns into a value carried around the pass loop
             B.off = true;
-            // binned primary pass (two-level worlds): this wave's 8x8 tile has a list of the objects its primary rays can touch
+            // binned primary pass: this wave's 8x8 tile has a list of the objects its primary rays can touch
             bool binned = false;
             uint32_t bin_cnt = 0;
             const uint32_t *bin_list = nullptr;
-            if constexpr (SRC == SRC_CULL2 && !PROBE) {
+            if constexpr (IS_CULL(SRC) && !PROBE) {
                 if (shared_origin && first) {
                     const auto &Pt = KP(P_arg);
                     if (Pt.tile_cnt != nullptr) {
@@ -1189,7 +1189,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     return true;
                 }, ro, rd, NoSkip{}, DIAG_PTR(6), DIAG_PTR(8), DIAG_PTR(10));
 #endif
-            } else if (SRC == SRC_CULL2 && !PROBE && shared_origin && first && binned) {
+            } else if (IS_CULL(SRC) && !PROBE && shared_origin && first && binned) {
                 // binned primary pass: the unbounded objects, then the tile's own list (k_bin_objects / k_bin_wide) — together
                 // every object this tile's rays can touch
                 const auto &Pb = KP(P_arg);

@@ -202,3 +202,79 @@ def test_world_ids_assigned_and_shared_ids_honoured(rtc, gpu, O, scenes):
         wu, _ = scenes.glass_cluster(n, size[0], size[1], id_modulus=0)
         assert not np.array_equal(gpu.upload(wu).render(cam), got)
         dw.close()
+
+
+# ------------------------------------------------------------------ binned primary pass
+def _ctx_env(rtc, **env):
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        for k, v in env.items():
+            os.environ[k] = str(v)
+        return rtc.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def test_binned_primary_pass_equals_the_group_walk(rtc, O, scenes):
+    """Two-level worlds take their primary rays' candidates from per-view tile lists (k_cell_bundles / k_bin_objects /
+    k_bin_wide) instead of walking the groups. Same conservative predicate, so the canvases must equal the walk's
+    (RTC_BINNING=0) and brute force bit for bit with identical ray counts — including the cases the lists cannot serve:
+    tiles whose list overflows (many objects behind few pixels), objects that cover most of the screen (deferred to
+    k_bin_wide), unbounded objects (planes: the sorted tables' prefix), row ranges that do not start on a tile row (no
+    binning), Camera::render's untraced last row/column, interleaved bands, several views per launch, and a reflective
+    world (first pass binned, secondary passes not)."""
+    import torch
+    rng = np.random.default_rng(77)
+    u = lambda a, b: float(rng.uniform(a, b))
+    w = rtc.World(rtc.light((-6.0, 9.0, -8.0)))
+    for i in range(700):
+        r = u(0.03, 0.3)
+        w.add_shape(rtc.sphere(rtc.Matrix.identity().scaling(r, r, r).translation(u(-8, 8), u(0, 6), u(-2, 25)),
+                               rtc.material(color=(u(0, 1), u(0, 1), u(0, 1)), specular=0.3, shininess=40.0,
+                                            reflective=(0.3 if i % 9 == 0 else 0.0))))
+    w.add_shape(rtc.sphere(rtc.Matrix.identity().scaling(30, 30, 30).translation(0, 0, 70), rtc.material(color=(0.2, 0.3, 0.9))))   # fills the view
+    w.add_shape(rtc.sphere(rtc.Matrix.identity().scaling(4, 4, 4).translation(1, 2, 6), rtc.material(color=(0.9, 0.3, 0.2))))       # wide
+    w.add_shape(rtc.plane(rtc.Matrix.identity(), rtc.material(specular=0.0, pattern=("checker", (0.3,) * 3, (0.7,) * 3, None))))
+    view = rtc.Matrix.make_view_transform((0.0, 2.0, -8.0), (0.0, 1.0, 5.0), (0.0, 1.0, 0.0))
+    ctx_bin, ctx_walk = rtc.Context(0), _ctx_env(rtc, RTC_BINNING=0)
+    dwb, dww = ctx_bin.upload(w), ctx_walk.upload(w)
+    for (W, H) in ((640, 360), (72, 45)):       # 72x45: hundreds of objects behind every tile -> lists overflow, tiles walk
+        cam = rtc.camera(W, H, 0.8, view)
+        for mode in (rtc.MODE_RENDER_ASYNC, rtc.MODE_RENDER):
+            a, sa = dwb.render(cam, mode, with_stats=True)
+            b, sb = dww.render(cam, mode, with_stats=True)
+            c, sc = dwb.render(cam, mode, flags=rtc.FLAG_NO_CULL, with_stats=True)
+            assert np.array_equal(a, b) and sa == sb and np.array_equal(a, c) and sa == sc, (W, H, mode)
+        # rows that do not start on a tile row (no binning), and one rank's bands (binning with a band stride)
+        cam = rtc.camera(W, H, 0.8, view)
+        full = dww.render(cam)
+        t = torch.zeros((H - 13, W, 3), dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        dwb.render_rows(cam, 13, H, t.data_ptr())
+        ctx_bin.synchronize()
+        assert np.array_equal(t.cpu().numpy(), full[13:])
+        nb = -(-H // 8)
+        per = -(-nb // 3) * 8
+        t = torch.zeros((2 * per, W, 3), dtype=torch.float64, device="cuda:0")
+        cam2 = rtc.camera(W, H, 0.75, rtc.Matrix.make_view_transform((1.0, 2.5, -7.0), (0.0, 1.0, 5.0), (0.0, 1.0, 0.0)))
+        dwb.render_views([cam, cam2], 1, 3, t.data_ptr(), per)
+        ctx_bin.synchronize()
+        th, full2 = t.cpu().numpy(), dww.render(cam2)
+        for k, band in enumerate(range(1, nb, 3)):
+            rows = min(8, H - band * 8)
+            assert np.array_equal(th[k * 8:k * 8 + rows], full[band * 8:band * 8 + rows])
+            assert np.array_equal(th[per + k * 8:per + k * 8 + rows], full2[band * 8:band * 8 + rows])
+    # against the oracle on sampled pixels of the larger frame
+    cam = rtc.camera(640, 360, 0.8, view)
+    a = dwb.render(cam)
+    arr = w.array()
+    for _ in range(300):
+        x, y = int(rng.integers(0, 640)), int(rng.integers(0, 360))
+        want = O.color_at(arr, len(w), w.light, rtc.ray_for_pixel(cam, x, y), 5)
+        assert np.max(np.abs(a[y, x] - want)) <= TIGHT_TOL, (x, y)
+    ctx_bin.close()
+    ctx_walk.close()
