@@ -206,6 +206,10 @@ void fill_world(RenderParams &P, const rtc_world *w) {
     P.orig_s = w->d_orig_s;
     P.gbound = w->d_gbound;
     P.idtab = w->d_idtab;
+    P.light_cnt = w->d_light_cnt;
+    P.light_list = w->d_light_list;
+    P.light_reach = w->light_reach;
+    P.n_unb = w->n_unb;
     P.ngroups = w->ngroups;
     P.n = w->n;
     for (int i = 0; i < 3; ++i) {
@@ -242,6 +246,7 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
         if (v >= 0 && v <= 4) ctx->force_src = v;
     }
     if (const char *e = std::getenv("RTC_BINNING")) ctx->binning = std::atoi(e) != 0;
+    if (const char *e = std::getenv("RTC_LIGHT_LISTS")) ctx->light_lists = std::atoi(e) != 0;
     if (const char *e = std::getenv("RTC_BIN_SMALL_VIEWS")) ctx->bin_small_views = (uint32_t)std::atoi(e);
     if (const char *e = std::getenv("RTC_TILE_CAP")) {
         const int v = std::atoi(e);
@@ -445,6 +450,29 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
          hipMemcpy(w->d_gbound, gbound.data(), sizeof(DevBound) * gbound.size(), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_idtab, idtab.data(), sizeof(DevIdEntry) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(w->d_prim, 0, sizeof(DevPrim) * na) == hipSuccess;
+    // light-space shadow lists (two-level worlds): every shadow segment ends at the light, so the objects a segment can meet
+    // are listed per direction cell of a cube map around the light, once per World. Reach = twice the far side of the
+    // farthest bounded object as seen from the light (longer segments fall back to the group walk).
+    if (ok && n > 256) {
+        double far = 0.;
+        for (uint32_t i = 0; i < n; ++i)
+            if (std::isfinite(bound[i].r)) {
+                const double dx = bound[i].cx - light->position[0], dy = bound[i].cy - light->position[1], dz = bound[i].cz - light->position[2];
+                far = std::fmax(far, std::sqrt(dx * dx + dy * dy + dz * dz) + bound[i].r);
+            }
+        const double reach = 2. * far;
+        if (std::isfinite(reach) && reach > 0. && reach < 1e30 && std::isfinite(light->position[0]) && std::isfinite(light->position[1]) &&
+            std::isfinite(light->position[2])) {
+            const size_t cells = 6u * (size_t)RTC_LIGHT_R * RTC_LIGHT_R, macros = 6u * (size_t)(RTC_LIGHT_R / 8u) * (RTC_LIGHT_R / 8u);
+            ok = hipMalloc(&w->d_light_cells, sizeof(DevTileBundle) * (cells + macros)) == hipSuccess &&
+                 hipMalloc(&w->d_light_cnt, sizeof(uint32_t) * cells) == hipSuccess &&
+                 hipMalloc(&w->d_light_list, sizeof(uint32_t) * cells * RTC_LIGHT_LIST_CAP) == hipSuccess &&
+                 rtc_launch_light_lists(n, w->d_bound, light->position, reach, w->d_light_cells, w->d_light_cells + cells, w->d_light_cnt,
+                                        w->d_light_list, ctx->stream) == hipSuccess &&
+                 hipStreamSynchronize(ctx->stream) == hipSuccess;
+            w->light_reach = reach;
+        }
+    }
     if (!ok) {
         rtc_world_destroy(w);
         return RTC_ERR_DEVICE;
@@ -475,6 +503,9 @@ void rtc_world_destroy(rtc_world *w) {
     if (w->d_tile_cnt) (void)hipFree(w->d_tile_cnt);
     if (w->d_tile_list) (void)hipFree(w->d_tile_list);
     if (w->d_bin_global) (void)hipFree(w->d_bin_global);
+    if (w->d_light_cells) (void)hipFree(w->d_light_cells);
+    if (w->d_light_cnt) (void)hipFree(w->d_light_cnt);
+    if (w->d_light_list) (void)hipFree(w->d_light_list);
     delete w;
 }
 
@@ -486,6 +517,7 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     RenderParams P;
     std::memset(&P, 0, sizeof P);
     fill_world(P, w);
+    if (!ctx->light_lists) P.light_cnt = nullptr;
     for (uint32_t v = 0; v < nviews; ++v) fill_camera(P, cam + v, v);
     P.nviews = nviews;
     P.view_rows = view_rows;
@@ -771,6 +803,7 @@ rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays
         RenderParams P;
         std::memset(&P, 0, sizeof P);
         fill_world(P, w);
+        if (!ctx->light_lists) P.light_cnt = nullptr;
         P.W = n; P.H = 1; P.y0 = 0; P.y1 = 1; P.mode = RTC_MODE_RENDER_ASYNC; P.samples = 1;
         P.out = d_rgb;
         P.counters = nullptr;

@@ -70,6 +70,16 @@ struct DevTileBundle {
 #define RTC_BIN_WIDE 16u
 #define RTC_BIN_WIDE_CAP 1024u
 
+// Light-space shadow lists (two-level worlds). Every shadow segment ends at the light (is_shadowed_by_light shape.rs:716-720),
+// so seen from the light it is a ray in some direction: a cube map of RTC_LIGHT_R x RTC_LIGHT_R direction cells per face
+// around the light, built ONCE per World, holds for each cell the objects a ray from the light in that cell's directions can
+// touch within `light_reach` (bundle_touches against the cell's cone, as everywhere). A wave's shadow pass then filters the
+// lists of the (typically one to four) cells its lanes' directions fall in with its own shadow bundle, instead of walking
+// every group sphere of the World. Cells whose list overflows, segments longer than light_reach and unbounded objects fall
+// back to the walk / are tested always.
+#define RTC_LIGHT_R 128u
+#define RTC_LIGHT_LIST_CAP 128u
+
 // Rounding note. The cull must never drop an object for which the REFERENCE ARITHMETIC reports an
 // intersection — including intersections that exist only because of rounding. The sphere test
 // evaluates disc = b*b - 4*a*c with b^2 and 4ac of size ~4a|o'|^2 (o' = object-space ray origin);
@@ -138,6 +148,10 @@ struct RenderParams {
     const uint32_t *tile_cnt;
     const uint32_t *tile_list;
     uint32_t tiles_x, tiles_y;
+    // light-space shadow lists (nullptr: none): per direction cell a counter and RTC_LIGHT_LIST_CAP insertion indices
+    const uint32_t *light_cnt;
+    const uint32_t *light_list;
+    double light_reach;
     const uint32_t *bin_wide;   // per view: [0] number of deferred wide objects (> RTC_BIN_WIDE_CAP: the lists are incomplete)
     uint32_t n_unb;             // unbounded objects = the first n_unb entries of isect_s / kind_s / orig_s
     uint32_t ngroups;

@@ -30,6 +30,7 @@ struct rtc_context {
     size_t canvas_bytes = 0;
     int force_src = -1;   // RTC_SRC env override (experiments)
     uint32_t tile_cap = 512;
+    bool light_lists = true; // RTC_LIGHT_LISTS=0: shadow passes of two-level worlds walk the groups (A/B)
     bool binning = true;  // RTC_BINNING=0: primary rays take the wave-level cull / group walk too (A/B)
     // one-level worlds (<= 256 objects) are binned only in launches of at least this many views (RTC_BIN_SMALL_VIEWS). Off by
     // default: measured on one box with 8 views per launch the render kernel gains 12 % (north star 0.0748 -> 0.0660 ms) but
@@ -56,6 +57,10 @@ struct rtc_world {
     mutable DevTileBundle *d_tile_bundles = nullptr, *d_macro_bundles = nullptr;
     mutable uint32_t *d_tile_cnt = nullptr, *d_tile_list = nullptr;
     uint32_t *d_bin_global = nullptr; // [RTC_MAX_VIEWS][1 + RTC_BIN_WIDE_CAP]: deferred wide objects per view
+    // light-space shadow lists (two-level worlds), built once at rtc_world_create
+    DevTileBundle *d_light_cells = nullptr;
+    uint32_t *d_light_cnt = nullptr, *d_light_list = nullptr;
+    double light_reach = 0.;
     uint32_t n_unb = 0;               // unbounded objects: the first n_unb entries of the Morton-sorted tables
     mutable size_t bin_tiles_cap = 0, bin_macros_cap = 0; // capacity in (view, tile) / (view, macro tile) entries
     uint32_t ngroups = 0;
@@ -67,6 +72,8 @@ struct rtc_world {
 extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound,
                                          DevTileBundle *tile_bundles, DevTileBundle *macro_bundles, uint32_t *cnt, uint32_t *list,
                                          uint32_t *wide, hipStream_t stream);
+extern "C" hipError_t rtc_launch_light_lists(uint32_t n, const DevBound *bound, const double light[3], double reach, DevTileBundle *cells,
+                                             DevTileBundle *macros, uint32_t *cnt, uint32_t *list, hipStream_t stream);
 extern "C" hipError_t rtc_launch_undeal(const void *staging, void *canvas, uint32_t nranks, uint32_t nframes, uint32_t H,
                                         uint32_t rows_max, size_t row_bytes, hipStream_t stream);
 

@@ -534,6 +534,20 @@ DEVI float bound_key(V3 apex, const DevBound &b) {
     return fmaxf(0.f, (dist - rad) * 0.999999f); // NaN / inf - inf -> 0: no bound
 }
 
+// Direction (from the light) -> cube-map cell. Face = the axis of the largest component (ties: x before y before z) and
+// its sign; (u, v) = the other two components over it, each in [-1, 1]; cell = floor((u + 1) * R / 2), clamped.
+DEVI uint32_t light_cell(V3 d) {
+    const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+    uint32_t a;
+    double m, u, v;
+    if (ax >= ay && ax >= az) { a = 0u; m = d.x; u = d.y; v = d.z; }
+    else if (ay >= az) { a = 1u; m = d.y; u = d.z; v = d.x; }
+    else { a = 2u; m = d.z; u = d.x; v = d.y; }
+    const double im = 1.0 / fabs(m);
+    const double fu = (u * im + 1.0) * (0.5 * RTC_LIGHT_R), fv = (v * im + 1.0) * (0.5 * RTC_LIGHT_R);
+    const int iu = (int)fmin(fmax(fu, 0.0), (double)(RTC_LIGHT_R - 1u)), iv = (int)fmin(fmax(fv, 0.0), (double)(RTC_LIGHT_R - 1u)); // NaN -> 0
+    return ((a * 2u + (m < 0. ? 1u : 0u)) * RTC_LIGHT_R + (uint32_t)iv) * RTC_LIGHT_R + (uint32_t)iu;
+}
 // Per-lane prefilter for INCOHERENT rays (reflection / refraction): can THIS lane's ray, for some
 // t >= 0, touch the object's bounding sphere? false => the exact test would find no entry with
 // t >= 0 for this lane. ~22 f64 instructions against 54+ for the exact test; the exact test is
@@ -1360,6 +1374,51 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             STAMP(5); // shadow bundle built
             DIAG(3, ballot(hit) != 0ull ? 1u : 0u);
             DIAG(4, (ballot(hit) != 0ull && Bs.off) ? 1u : 0u);
+            // Light-space shadow lists (two-level worlds): instead of walking every group sphere, filter the lists of the
+            // direction cells (around the light) this wave's segments fall in with the wave's own shadow bundle.
+            bool listed = false;
+            if constexpr (SRC == SRC_CULL2) {
+                const auto &Pl = KP(P_arg);
+                if (Pl.light_cnt != nullptr && !Bs.off && Bs.tmax <= Pl.light_reach && ballot(hit) != 0ull) {
+                    const uint32_t cid = hit ? light_cell(vneg(sdir)) : 0u;
+                    listed = true;
+                    for (unsigned long long todo = ballot(hit); todo;) { // a cell whose list overflowed is incomplete: walk instead
+                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cid, (int)__builtin_ctzll(todo));
+                        todo &= ~ballot(hit && cid == c);
+                        if (Pl.light_cnt[c] > RTC_LIGHT_LIST_CAP) { listed = false; break; }
+                    }
+                    if (listed) {
+                        for (uint32_t k = 0; k < Pl.n_unb && ballot(sh_pending) != 0ull; ++k) { // unbounded objects: never listed
+                            DIAG(5, 1u);
+                            if (sh_pending && occludes_world(T.kind_s[k], T.isect_s[k].m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
+                        }
+                        for (unsigned long long todo = ballot(hit); todo && ballot(sh_pending) != 0ull;) {
+                            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cid, (int)__builtin_ctzll(todo));
+                            todo &= ~ballot(hit && cid == c);
+                            const uint32_t nl = Pl.light_cnt[c];
+                            const uint32_t *ll = Pl.light_list + (size_t)c * RTC_LIGHT_LIST_CAP;
+                            for (uint32_t base = 0; base < nl && ballot(sh_pending) != 0ull; base += 64u) {
+                                const uint32_t e = base + lane;
+                                uint32_t idx = 0u;
+                                bool cand = false;
+                                if (e < nl) { idx = ll[e]; cand = bundle_touches(Bs, T.bound[idx]); }
+                                DIAG_FILTER(DIAG_PTR(9));
+                                unsigned long long mask = ballot(cand);
+                                while (mask) {
+                                    const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)idx, (int)__builtin_ctzll(mask));
+                                    mask &= mask - 1ull;
+                                    DIAG_FILTER(DIAG_PTR(11));
+                                    if (ballot(sh_pending && ray_touches(over, sdir, T.bound[j])) == 0ull) continue;
+                                    DIAG(5, 1u);
+                                    if (sh_pending && occludes_world(T.kind[j], T.isect[j].m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
+                                    if (ballot(sh_pending) == 0ull) break;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (!listed)
             for_each_object<SRC, RTC_SHADOW_LANE_FILTER(SRC, REFL)>(P, T, L, sh_pending, Bs, [&](int j, auto m, uint32_t kind, auto pr) {
                 DIAG(5, 1u);
                 if (sh_pending) {
@@ -1928,6 +1987,90 @@ extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews
         hipLaunchKernelGGL(k_bin_wide, dim3(nviews * RTC_BIN_WIDE_WORKERS * supers), dim3(64), 0, stream, Q, bound, (const DevTileBundle *)tile_bundles,
                            (const DevTileBundle *)macro_bundles, (const DevTileBundle *)super_bundles, cnt, list, (const uint32_t *)wide);
     }
+    return hipGetLastError();
+}
+
+// ---- light-space shadow lists (rtc_device.h) -------------------------------------------------------------------------
+// Unit direction through cube-map coordinates (u, v) of face `face`.
+DEVI void light_dir(uint32_t face, float u, float v, float &x, float &y, float &z) {
+    const float s = (face & 1u) ? -1.f : 1.f;
+    const uint32_t a = face >> 1;
+    float c[3];
+    c[a] = s; c[(a + 1u) % 3u] = u; c[(a + 2u) % 3u] = v;
+    const float il = __builtin_amdgcn_rsqf(c[0] * c[0] + c[1] * c[1] + c[2] * c[2]);
+    x = c[0] * il; y = c[1] * il; z = c[2] * il;
+}
+// One thread per cell or per macro cell (8x8 cells): the cone of its directions (axis through the centre, half-angle to
+// the farthest of the four corners — the angle to the axis is quasi-convex over the square — with make_bundle's margins).
+__global__ void __launch_bounds__(256) k_light_cells(DevTileBundle *__restrict__ cells, DevTileBundle *__restrict__ macros, uint32_t *__restrict__ cnt) {
+#pragma clang fp contract(fast)
+    constexpr uint32_t R = RTC_LIGHT_R, M = RTC_LIGHT_R / 8u;
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t g, span;
+    DevTileBundle *out;
+    if (i < 6u * R * R) { g = R; span = 1u; out = cells; cnt[i] = 0u; }
+    else if ((i -= 6u * R * R) < 6u * M * M) { g = M; span = 8u; out = macros; }
+    else return;
+    const uint32_t face = i / (g * g), ix = (i % g) * span, iy = ((i / g) % g) * span;
+    const float u0 = (float)ix * (2.f / R) - 1.f, u1 = (float)(ix + span) * (2.f / R) - 1.f;
+    const float v0 = (float)iy * (2.f / R) - 1.f, v1 = (float)(iy + span) * (2.f / R) - 1.f;
+    float ax, ay, az;
+    light_dir(face, 0.5f * (u0 + u1), 0.5f * (v0 + v1), ax, ay, az);
+    const float cu[4] = {u0, u1, u0, u1}, cv[4] = {v0, v0, v1, v1};
+    float q2max = 0.f;
+    for (int k = 0; k < 4; ++k) {
+        float fx, fy, fz;
+        light_dir(face, cu[k], cv[k], fx, fy, fz);
+        const float ux = ay * fz - az * fy, uy = az * fx - ax * fz, uz = ax * fy - ay * fx;
+        q2max = fmaxf(q2max, ux * ux + uy * uy + uz * uz);
+    }
+    DevTileBundle r;
+    r.ax = ax; r.ay = ay; r.az = az;
+    r.sinT = __builtin_sqrtf(q2max) * 1.001f + 1e-5f; // + the f64 -> cell rounding of a direction on a cell border
+    r.cosT = __builtin_sqrtf(fmaxf(0.f, 1.f - r.sinT * r.sinT));
+    r.off = r.sinT < 0.7f ? 0u : 1u;
+    out[i] = r;
+}
+DEVI Bundle light_bundle_of(const DevTileBundle &t, V3 apex, double reach) { // rays FROM the light, reach-limited (rho 0)
+    Bundle B = bundle_of(t, apex);
+    B.tmax = reach;
+    B.spread = reach; // the exact rays start at the far end (DevBound rounding note)
+    return B;
+}
+// One wave per object: macro cells (8x8 cells) 64 per step, then the cells of the touched macro cells.
+__global__ void __launch_bounds__(64) k_light_bin(uint32_t n, const DevBound *__restrict__ bound, double lx, double ly, double lz, double reach,
+                                                   const DevTileBundle *__restrict__ cells, const DevTileBundle *__restrict__ macros,
+                                                   uint32_t *__restrict__ cnt, uint32_t *__restrict__ list) {
+    constexpr uint32_t R = RTC_LIGHT_R, M = RTC_LIGHT_R / 8u;
+    const uint32_t j = blockIdx.x, lane = threadIdx.x;
+    if (j >= n) return;
+    const DevBound b = bound[j];
+    if (!(b.r < __builtin_inf())) return; // unbounded: every shadow pass tests it anyway
+    const V3 o = mk(lx, ly, lz);
+    for (uint32_t mbase = 0; mbase < 6u * M * M; mbase += 64u) {
+        const uint32_t m = mbase + lane;
+        bool tm = false;
+        if (m < 6u * M * M) tm = bundle_touches(light_bundle_of(macros[m], o, reach), b);
+        unsigned long long mmask = ballot(tm);
+        while (mmask) {
+            const uint32_t msel = mbase + (uint32_t)__builtin_ctzll(mmask);
+            mmask &= mmask - 1ull;
+            const uint32_t face = msel / (M * M), mx = msel % M, my = (msel / M) % M;
+            const uint32_t cell = (face * R + my * 8u + (lane >> 3)) * R + mx * 8u + (lane & 7u);
+            if (bundle_touches(light_bundle_of(cells[cell], o, reach), b)) {
+                const uint32_t slot = atomicAdd(cnt + cell, 1u);
+                if (slot < RTC_LIGHT_LIST_CAP) list[(size_t)cell * RTC_LIGHT_LIST_CAP + slot] = j;
+            }
+        }
+    }
+}
+
+extern "C" hipError_t rtc_launch_light_lists(uint32_t n, const DevBound *bound, const double light[3], double reach, DevTileBundle *cells,
+                                             DevTileBundle *macros, uint32_t *cnt, uint32_t *list, hipStream_t stream) {
+    constexpr uint32_t R = RTC_LIGHT_R, M = RTC_LIGHT_R / 8u;
+    hipLaunchKernelGGL(k_light_cells, dim3((6u * R * R + 6u * M * M + 255u) / 256u), dim3(256), 0, stream, cells, macros, cnt);
+    if (n) hipLaunchKernelGGL(k_light_bin, dim3(n), dim3(64), 0, stream, n, bound, light[0], light[1], light[2], reach, (const DevTileBundle *)cells,
+                              (const DevTileBundle *)macros, cnt, list);
     return hipGetLastError();
 }
 

@@ -219,10 +219,12 @@ def _ctx_env(rtc, **env):
                 os.environ[k] = v
 
 
-def test_binned_primary_pass_equals_the_group_walk(rtc, O, scenes):
+def test_binned_primary_pass_and_light_lists_equal_the_group_walk(rtc, O, scenes):
     """Two-level worlds take their primary rays' candidates from per-view tile lists (k_cell_bundles / k_bin_objects /
-    k_bin_wide) instead of walking the groups. Same conservative predicate, so the canvases must equal the walk's
-    (RTC_BINNING=0) and brute force bit for bit with identical ray counts — including the cases the lists cannot serve:
+    k_bin_wide) and their shadow rays' candidates from the light-space direction-cell lists built once per World
+    (k_light_cells / k_light_bin), instead of walking the groups. Same conservative predicate, so the canvases must equal
+    the walk's (RTC_BINNING=0 RTC_LIGHT_LISTS=0) and brute force bit for bit with identical ray counts — including the cases
+    the lists cannot serve:
     tiles whose list overflows (many objects behind few pixels), objects that cover most of the screen (deferred to
     k_bin_wide), unbounded objects (planes: the sorted tables' prefix), row ranges that do not start on a tile row (no
     binning), Camera::render's untraced last row/column, interleaved bands, several views per launch, and a reflective
@@ -240,7 +242,7 @@ def test_binned_primary_pass_equals_the_group_walk(rtc, O, scenes):
     w.add_shape(rtc.sphere(rtc.Matrix.identity().scaling(4, 4, 4).translation(1, 2, 6), rtc.material(color=(0.9, 0.3, 0.2))))       # wide
     w.add_shape(rtc.plane(rtc.Matrix.identity(), rtc.material(specular=0.0, pattern=("checker", (0.3,) * 3, (0.7,) * 3, None))))
     view = rtc.Matrix.make_view_transform((0.0, 2.0, -8.0), (0.0, 1.0, 5.0), (0.0, 1.0, 0.0))
-    ctx_bin, ctx_walk = rtc.Context(0), _ctx_env(rtc, RTC_BINNING=0)
+    ctx_bin, ctx_walk = rtc.Context(0), _ctx_env(rtc, RTC_BINNING=0, RTC_LIGHT_LISTS=0)
     dwb, dww = ctx_bin.upload(w), ctx_walk.upload(w)
     for (W, H) in ((640, 360), (72, 45)):       # 72x45: hundreds of objects behind every tile -> lists overflow, tiles walk
         cam = rtc.camera(W, H, 0.8, view)
