@@ -438,14 +438,16 @@ def measure_dropin(rtc, np, torch, dev_index, world, cam, grouped, group, gworld
         d = c.upload(world)
         pageable = np.empty((H, W, 3), dtype=np.float64)
         pageable[...] = 0.0
+        out["rtc_render_fresh_canvas_ms"] = per_frame(lambda: d.render(cam))   # a NEW host canvas per frame (Canvas::new per call): first-touch page faults included
         out["rtc_render_pageable_ms"] = per_frame(lambda: d.render(cam, out=pageable))
         rtc.host_register(pageable)
         out["rtc_render_registered_ms"] = per_frame(lambda: d.render(cam, out=pageable))
         rtc.host_unregister(pageable)
         pinned = rtc.host_canvas(H, W)
         out["rtc_render_pinned_ms"] = per_frame(lambda: d.render(cam, out=pinned))
-        out["note"] = ("ms per 1-camera frame INCLUDING the copy of the f64 canvas to host memory over PCIe (never `value`): pageable = a plain "
-                       "allocation, registered = the same allocation after rtc_host_register, pinned = rtc_host_alloc")
+        out["note"] = ("ms per 1-camera frame INCLUDING the copy of the f64 canvas to host memory over PCIe (never `value`): fresh_canvas = a new "
+                       "allocation every frame (what `Canvas::new` per call costs: first-touch page faults), pageable = one plain allocation reused, "
+                       "registered = the same after rtc_host_register, pinned = rtc_host_alloc")
         d.close()
         c.close()
     else:
