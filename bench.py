@@ -439,13 +439,6 @@ def measure_dropin(rtc, np, torch, dev_index, world, cam, grouped, group, gworld
         pageable = np.empty((H, W, 3), dtype=np.float64)
         pageable[...] = 0.0
         out["rtc_render_fresh_canvas_ms"] = per_frame(lambda: d.render(cam))   # a NEW host canvas per frame (Canvas::new per call): first-touch page faults included
-        os.environ["RTC_NO_STAGING"] = "1"          # the runtime's own pageable path, for comparison (read at context creation)
-        c2 = rtc.Context(dev_index)
-        d2 = c2.upload(world)
-        out["rtc_render_fresh_canvas_runtime_path_ms"] = per_frame(lambda: d2.render(cam))
-        d2.close()
-        c2.close()
-        del os.environ["RTC_NO_STAGING"]
         out["rtc_render_pageable_ms"] = per_frame(lambda: d.render(cam, out=pageable))
         rtc.host_register(pageable)
         out["rtc_render_registered_ms"] = per_frame(lambda: d.render(cam, out=pageable))
@@ -453,9 +446,7 @@ def measure_dropin(rtc, np, torch, dev_index, world, cam, grouped, group, gworld
         pinned = rtc.host_canvas(H, W)
         out["rtc_render_pinned_ms"] = per_frame(lambda: d.render(cam, out=pinned))
         out["note"] = ("ms per 1-camera frame INCLUDING the copy of the f64 canvas to host memory over PCIe (never `value`): fresh_canvas = a new "
-                       "allocation every frame (what `Canvas::new` per call costs: first-touch page faults; librtc stages pageable canvases through its own "
-                       "page-locked buffer and copies on with a few host threads — `_runtime_path` = the HIP runtime's own pageable copy instead), "
-                       "pageable = one plain allocation reused, "
+                       "allocation every frame (what `Canvas::new` per call costs: first-touch page faults), pageable = one plain allocation reused, "
                        "registered = the same after rtc_host_register, pinned = rtc_host_alloc")
         d.close()
         c.close()

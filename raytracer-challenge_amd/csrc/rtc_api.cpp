@@ -6,8 +6,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <atomic>
-#include <thread>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -247,7 +245,6 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
         const int v = std::atoi(e);
         if (v >= 0 && v <= 4) ctx->force_src = v;
     }
-    if (const char *e = std::getenv("RTC_NO_STAGING")) ctx->no_staging = std::atoi(e) != 0;
     if (const char *e = std::getenv("RTC_BINNING")) ctx->binning = std::atoi(e) != 0;
     if (const char *e = std::getenv("RTC_LIGHT_LISTS")) ctx->light_lists = std::atoi(e) != 0;
     if (const char *e = std::getenv("RTC_BIN_SMALL_VIEWS")) ctx->bin_small_views = (uint32_t)std::atoi(e);
@@ -265,8 +262,6 @@ void rtc_context_destroy(rtc_context *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_canvas) (void)hipFree(ctx->d_canvas);
-    if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-    for (hipEvent_t e : ctx->stage_events) (void)hipEventDestroy(e);
     for (auto &pair : ctx->ev)
         for (hipEvent_t e : pair)
             if (e) (void)hipEventDestroy(e);
@@ -754,61 +749,10 @@ rtc_status rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *ca
     rtc_status st = RTC_OK;
     if (stats) st = rtc_stats_reset(ctx);
     if (st == RTC_OK) st = rtc_render_rows(ctx, w, cam, mode, 0, cam->vsize, d, nullptr, flags);
-    if (st != RTC_OK) return st;
-    // `rgb` page-locked (rtc_host_alloc, rtc_host_register): one DMA at link speed. Pageable memory: the DMA goes, in chunks,
-    // into the context's own page-locked staging buffer, and a few host threads copy each chunk on as soon as its event
-    // fires — a fresh `Vec<Color>` (Canvas::new per call) is dominated by first-touch page faults, which the runtime's own
-    // pageable path takes on ONE thread (4.8 ms per 1080p frame against 1.0 ms of PCIe).
-    hipPointerAttribute_t attr;
-    bool pinned = hipPointerGetAttributes(&attr, rgb) == hipSuccess && (attr.type == hipMemoryTypeHost || attr.type == hipMemoryTypeManaged);
-    (void)hipGetLastError(); // an unknown (pageable) pointer is reported as an error: clear it
-    if (ctx->no_staging) pinned = true;
-    if (pinned) {
-        if (hipMemcpyAsync(rgb, d, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
-        if (st == RTC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
-    } else {
-        if (ctx->stage_bytes < bytes) {
-            if (ctx->h_stage) (void)hipHostFree(ctx->h_stage);
-            ctx->h_stage = nullptr;
-            ctx->stage_bytes = 0;
-            HIP_TRY(hipHostMalloc(&ctx->h_stage, bytes, hipHostMallocDefault));
-            ctx->stage_bytes = bytes;
-        }
-        constexpr size_t CHUNK = 4u << 20;
-        const size_t nchunks = (bytes + CHUNK - 1) / CHUNK;
-        while (ctx->stage_events.size() < nchunks) {
-            hipEvent_t e;
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ctx->stage_events.push_back(e);
-        }
-        char *src = static_cast<char *>(ctx->h_stage), *dst = reinterpret_cast<char *>(rgb);
-        const char *dev = reinterpret_cast<const char *>(d);
-        for (size_t c = 0; c < nchunks && st == RTC_OK; ++c) {
-            const size_t off = c * CHUNK, len = std::min(CHUNK, bytes - off);
-            if (hipMemcpyAsync(src + off, dev + off, len, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-                hipEventRecord(ctx->stage_events[c], ctx->stream) != hipSuccess)
-                st = RTC_ERR_DEVICE;
-        }
-        if (st == RTC_OK) {
-            const unsigned hw = std::thread::hardware_concurrency();
-            const size_t nthreads = std::max<size_t>(1, std::min<size_t>({nchunks, hw ? hw : 4u, (size_t)16}));
-            std::atomic<int> failed{0};
-            auto worker = [&](size_t t) {
-                (void)hipSetDevice(ctx->device);
-                for (size_t c = t; c < nchunks; c += nthreads) {
-                    if (hipEventSynchronize(ctx->stage_events[c]) != hipSuccess) { failed = 1; return; }
-                    const size_t off = c * CHUNK, len = std::min(CHUNK, bytes - off);
-                    std::memcpy(dst + off, src + off, len);
-                }
-            };
-            std::vector<std::thread> pool;
-            for (size_t t = 1; t < nthreads; ++t) pool.emplace_back(worker, t);
-            worker(0);
-            for (std::thread &th : pool) th.join();
-            if (failed) st = RTC_ERR_DEVICE;
-        }
-        if (hipStreamSynchronize(ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
-    }
+    // `rgb` from rtc_host_alloc (page-locked) is filled by one DMA at link speed; pageable memory
+    // goes through the runtime's bounce buffers (several times slower)
+    if (st == RTC_OK && hipMemcpyAsync(rgb, d, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
+    if (st == RTC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
     if (st == RTC_OK && stats) st = rtc_stats_read(ctx, stats);
     return st;
 }

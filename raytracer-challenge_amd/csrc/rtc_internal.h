@@ -28,11 +28,6 @@ struct rtc_context {
     // device canvas of rtc_render (host-canvas entry point): grow-only, reused between frames
     double *d_canvas = nullptr;
     size_t canvas_bytes = 0;
-    // page-locked staging buffer + one event per 4 MB chunk for rtc_render into PAGEABLE host canvases
-    void *h_stage = nullptr;
-    size_t stage_bytes = 0;
-    std::vector<hipEvent_t> stage_events;
-    bool no_staging = false; // RTC_NO_STAGING=1: hand pageable canvases to the runtime's own path (A/B)
     int force_src = -1;   // RTC_SRC env override (experiments)
     uint32_t tile_cap = 512;
     bool light_lists = true; // RTC_LIGHT_LISTS=0: shadow passes of two-level worlds walk the groups (A/B)
