@@ -544,13 +544,13 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
         // Camera::resample traces `antialiasing_samples` more rays (camera.rs:87); u8 in the reference
         P.resample_n = (flags & RTC_FLAG_AA_RESAMPLE) ? (cam->samples & 0xffu) : 0u;
     }
-    // binned primary pass (two-level worlds, one ray per pixel, tile rows aligned with the image's): three small kernels put
+    // binned primary pass (two-level worlds, tile rows aligned with the image's): three small kernels put
     // every object on the list of each 8x8 tile its bounding sphere can touch (same conservative predicate as the wave-level
     // cull), so the render kernel's primary pass runs exact tests on a short list instead of walking the groups
     // (small worlds, one-level cull: off unless RTC_BIN_SMALL_VIEWS says otherwise — the three extra launches cost about
     // what a 100-object frame's primary cull saves)
     const bool bin_this = (src == SRC_CULL2) || (src == SRC_CULL && nviews >= ctx->bin_small_views);
-    if (bin_this && ctx->binning && P.samples == 1u && (y0 % 8u) == 0u && w->n != 0u && w->d_bin_global) {
+    if (bin_this && ctx->binning && (y0 % 8u) == 0u && w->n != 0u && w->d_bin_global) {
         const uint32_t tiles_x = (cam->hsize + 7u) / 8u, tiles_y = (cam->vsize + 7u) / 8u;
         const uint32_t macros_x = (tiles_x + 7u) / 8u, macros_y = (tiles_y + 7u) / 8u;
         // macro tiles and super tiles (8x8 macro tiles) share one buffer

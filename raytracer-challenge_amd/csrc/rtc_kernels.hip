@@ -1789,9 +1789,9 @@ __global__ void k_arith(uint32_t op, const double *a, const double *b, uint32_t 
 // ---- binned primary pass: per-view tile lists (DevTileBundle, rtc_device.h) ---------------------------------------
 // Primary ray of pixel (px, py) of one camera: Camera::ray_for_pixel_offset(x, 0.5, y, 0.5) camera.rs:64-76, the
 // expression k_trace evaluates.
-DEVI V3 primary_dir(const DevCamera &C, V3 cam_origin, uint32_t px, uint32_t py) {
-    const double xoffset = ((double)px + 0.5) * C.pixel_size;
-    const double yoffset = ((double)py + 0.5) * C.pixel_size;
+DEVI V3 primary_dir(const DevCamera &C, V3 cam_origin, uint32_t px, uint32_t py, double xo = 0.5, double yo = 0.5) {
+    const double xoffset = ((double)px + xo) * C.pixel_size;
+    const double yoffset = ((double)py + yo) * C.pixel_size;
     const double world_x = C.half_width - xoffset;
     const double world_y = C.half_height - yoffset;
     const V3 pixel = xpoint(C.vinv, mk(world_x, world_y, -1.));
@@ -1829,7 +1829,8 @@ DEVI bool dir_f32(V3 d, float &fx, float &fy, float &fz) {
 // plane and a fixed axis is a quasi-convex function of the pixel position (its sub-level sets are the interiors of conic
 // sections), so over the cell's rectangle of pixel centres it peaks at a corner; the reference arithmetic's rounding
 // (1e-16) and the f32 conversion (6e-8) sit far inside make_bundle's margins (sinT * 1.001 + 4e-6). All pixels inside the
-// image count: a superset of the lanes Camera::render traces. Tile threads also clear their tile's list counter.
+// image count: a superset of the lanes Camera::render traces; the corners are those of the pixel AREAS, so every
+// sub-pixel offset is inside too. Tile threads also clear their tile's list counter.
 __global__ void __launch_bounds__(256) k_cell_bundles(const BinParams Q, DevTileBundle *__restrict__ tiles_out,
                                                       DevTileBundle *__restrict__ macros_out, DevTileBundle *__restrict__ supers_out,
                                                       uint32_t *__restrict__ cnt, uint32_t *__restrict__ wide) {
@@ -1852,10 +1853,12 @@ __global__ void __launch_bounds__(256) k_cell_bundles(const BinParams Q, DevTile
     bool good = finite3(o) && dir_f32(primary_dir(C, o, min(x0 + cell / 2u - 1u, x1), min(y0 + cell / 2u - 1u, y1)), ax, ay, az);
     float q2max = 0.f;
     bool narrow = true;
+    // corners of the cell's pixel AREA (offsets 0 and 1, not the pixel centres): the cone then also holds every
+    // anti-aliasing sub-sample and resample ray of its pixels (camera.rs:98-105: offsets in [0, 1))
     const uint32_t cx[4] = {x0, x1, x0, x1}, cy[4] = {y0, y0, y1, y1};
     for (int k = 0; k < 4; ++k) {
         float fx, fy, fz;
-        good = dir_f32(primary_dir(C, o, cx[k], cy[k]), fx, fy, fz) && good;
+        good = dir_f32(primary_dir(C, o, cx[k], cy[k], (k & 1) ? 1.0 : 0.0, (k & 2) ? 1.0 : 0.0), fx, fy, fz) && good;
         const float dotv = ax * fx + ay * fy + az * fz;
         const float ux = ay * fz - az * fy, uy = az * fx - ax * fz, uz = ax * fy - ay * fx;
         q2max = fmaxf(q2max, ux * ux + uy * uy + uz * uz);

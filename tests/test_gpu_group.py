@@ -270,6 +270,14 @@ def test_binned_primary_pass_and_light_lists_equal_the_group_walk(rtc, O, scenes
             rows = min(8, H - band * 8)
             assert np.array_equal(th[k * 8:k * 8 + rows], full[band * 8:band * 8 + rows])
             assert np.array_equal(th[per + k * 8:per + k * 8 + rows], full2[band * 8:band * 8 + rows])
+    # anti-aliased renders are binned too (the tile cones span the pixel areas): sub-samples and the resample
+    cam = rtc.camera(200, 120, 0.8, view, samples=3)
+    for flags in (0, rtc.FLAG_AA_RESAMPLE):
+        a, sa = dwb.render(cam, flags=flags, with_stats=True)
+        b, sb = dww.render(cam, flags=flags, with_stats=True)
+        assert np.array_equal(a, b) and sa == sb and sa["pixels_resample"] > 0, flags
+    want, ost = O.render(w.array(), len(w), w.light, cam, mode=1, nthreads=8, want_stats=True, flags=rtc.FLAG_AA_RESAMPLE)
+    assert sa == ost and np.max(np.abs(a - want)) <= TIGHT_TOL
     # against the oracle on sampled pixels of the larger frame
     cam = rtc.camera(640, 360, 0.8, view)
     a = dwb.render(cam)
