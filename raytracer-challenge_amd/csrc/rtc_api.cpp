@@ -449,7 +449,8 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
          hipMemcpy(w->d_orig_s, orig_s.data(), sizeof(uint32_t) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_gbound, gbound.data(), sizeof(DevBound) * gbound.size(), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_idtab, idtab.data(), sizeof(DevIdEntry) * na, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemset(w->d_prim, 0, sizeof(DevPrim) * na) == hipSuccess;
+         hipMemset(w->d_prim, 0, sizeof(DevPrim) * na) == hipSuccess &&
+         hipMemset(w->d_bin_global, 0, sizeof(uint32_t) * RTC_MAX_VIEWS * (RTC_BIN_WIDE_CAP + 1u)) == hipSuccess;
     // light-space shadow lists (two-level worlds): every shadow segment ends at the light, so the objects a segment can meet
     // are listed per direction cell of a cube map around the light, once per World. Reach = twice the far side of the
     // farthest bounded object as seen from the light (longer segments fall back to the group walk).

@@ -34,7 +34,9 @@ struct rtc_context {
     bool binning = true;  // RTC_BINNING=0: primary rays take the wave-level cull / group walk too (A/B)
     // one-level worlds (<= 256 objects) are binned only in launches of at least this many views (RTC_BIN_SMALL_VIEWS). Off by
     // default: measured on one box with 8 views per launch the render kernel gains 12 % (north star 0.0748 -> 0.0660 ms) but
-    // the three extra launches take most of it back (wall 0.0757 -> 0.0732), C2 loses (0.0617 -> 0.0644), C4 gains 3 %
+    // the three extra launches take most of it back (wall 0.0757 -> 0.0732), C2 loses (0.0617 -> 0.0644), C4 gains 3 %.
+    // A single-launch form that computes the cones on the fly (no tables) was tried as well: the kernel gains the same
+    // 13 % and the launch costs the same 9 us per frame (profiles/r02_exp_binned_small_worlds.log)
     uint32_t bin_small_views = 0xffffffffu;
 };
 

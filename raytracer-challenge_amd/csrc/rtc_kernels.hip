@@ -1823,29 +1823,9 @@ DEVI bool dir_f32(V3 d, float &fx, float &fy, float &fz) {
     return finite3(d) && l2 > 1e-30f && l2 < 1e30f;
 }
 
-// One THREAD per (view, cell) for all three levels at once — tiles of 8x8 pixels, macro tiles of 64x64, super tiles of
-// 512x512: the cone of the cell's primary rays with make_bundle's arithmetic and margins, from five rays instead of all:
-// the axis ray (a pixel near the cell's centre) and the four corner pixels. The angle between a ray through the image
-// plane and a fixed axis is a quasi-convex function of the pixel position (its sub-level sets are the interiors of conic
-// sections), so over the cell's rectangle of pixel centres it peaks at a corner; the reference arithmetic's rounding
-// (1e-16) and the f32 conversion (6e-8) sit far inside make_bundle's margins (sinT * 1.001 + 4e-6). All pixels inside the
-// image count: a superset of the lanes Camera::render traces; the corners are those of the pixel AREAS, so every
-// sub-pixel offset is inside too. Tile threads also clear their tile's list counter.
-__global__ void __launch_bounds__(256) k_cell_bundles(const BinParams Q, DevTileBundle *__restrict__ tiles_out,
-                                                      DevTileBundle *__restrict__ macros_out, DevTileBundle *__restrict__ supers_out,
-                                                      uint32_t *__restrict__ cnt, uint32_t *__restrict__ wide) {
+// The cone of the primary rays of the `cell` x `cell` pixel block at (x0, y0), clipped to the image (see k_cell_bundles).
+DEVI DevTileBundle cell_cone(const BinParams &Q, uint32_t view, uint32_t x0, uint32_t y0, uint32_t cell) {
 #pragma clang fp contract(fast)
-    const uint32_t nt = Q.nviews * Q.tiles_x * Q.tiles_y, nm = Q.nviews * Q.macros_x * Q.macros_y, ns = Q.nviews * Q.supers_x * Q.supers_y;
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < Q.nviews * (RTC_BIN_WIDE_CAP + 1u)) wide[i] = 0u; // the views' lists of deferred (wide) objects: count + entries
-    uint32_t gx, gy, cell;
-    DevTileBundle *out;
-    if (i < nt) { gx = Q.tiles_x; gy = Q.tiles_y; cell = 8u; out = tiles_out; cnt[i] = 0u; }
-    else if ((i -= nt) < nm) { gx = Q.macros_x; gy = Q.macros_y; cell = 64u; out = macros_out; }
-    else if ((i -= nm) < ns) { gx = Q.supers_x; gy = Q.supers_y; cell = 512u; out = supers_out; }
-    else return;
-    const uint32_t view = i / (gx * gy), t = i % (gx * gy);
-    const uint32_t x0 = (t % gx) * cell, y0 = (t / gx) * cell;
     const uint32_t x1 = min(x0 + cell - 1u, Q.W - 1u), y1 = min(y0 + cell - 1u, Q.H - 1u);
     const DevCamera &C = Q.views[view];
     const V3 o = xpoint(C.vinv, mk(0., 0., 0.));
@@ -1869,7 +1849,32 @@ __global__ void __launch_bounds__(256) k_cell_bundles(const BinParams Q, DevTile
     r.sinT = __builtin_sqrtf(q2max) * 1.001f + 4e-6f;
     r.cosT = __builtin_sqrtf(fmaxf(0.f, 1.f - r.sinT * r.sinT));
     r.off = (good && narrow && r.sinT < 0.98f) ? 0u : 1u; // wide or odd cells: every object is a candidate
-    out[i] = r;
+    return r;
+}
+
+// One THREAD per (view, cell) for all three levels at once — tiles of 8x8 pixels, macro tiles of 64x64, super tiles of
+// 512x512: the cone of the cell's primary rays with make_bundle's arithmetic and margins, from five rays instead of all:
+// the axis ray (a pixel near the cell's centre) and the four corner pixels. The angle between a ray through the image
+// plane and a fixed axis is a quasi-convex function of the pixel position (its sub-level sets are the interiors of conic
+// sections), so over the cell's rectangle of pixel centres it peaks at a corner; the reference arithmetic's rounding
+// (1e-16) and the f32 conversion (6e-8) sit far inside make_bundle's margins (sinT * 1.001 + 4e-6). All pixels inside the
+// image count: a superset of the lanes Camera::render traces; the corners are those of the pixel AREAS, so every
+// sub-pixel offset is inside too. Tile threads also clear their tile's list counter.
+__global__ void __launch_bounds__(256) k_cell_bundles(const BinParams Q, DevTileBundle *__restrict__ tiles_out,
+                                                      DevTileBundle *__restrict__ macros_out, DevTileBundle *__restrict__ supers_out,
+                                                      uint32_t *__restrict__ cnt, uint32_t *__restrict__ wide) {
+#pragma clang fp contract(fast)
+    const uint32_t nt = Q.nviews * Q.tiles_x * Q.tiles_y, nm = Q.nviews * Q.macros_x * Q.macros_y, ns = Q.nviews * Q.supers_x * Q.supers_y;
+    uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < Q.nviews * (RTC_BIN_WIDE_CAP + 1u)) wide[i] = 0u; // the views' lists of deferred (wide) objects: count + entries
+    uint32_t gx, gy, cell;
+    DevTileBundle *out;
+    if (i < nt) { gx = Q.tiles_x; gy = Q.tiles_y; cell = 8u; out = tiles_out; cnt[i] = 0u; }
+    else if ((i -= nt) < nm) { gx = Q.macros_x; gy = Q.macros_y; cell = 64u; out = macros_out; }
+    else if ((i -= nm) < ns) { gx = Q.supers_x; gy = Q.supers_y; cell = 512u; out = supers_out; }
+    else return;
+    const uint32_t view = i / (gx * gy), t = i % (gx * gy);
+    out[i] = cell_cone(Q, view, (t % gx) * cell, (t / gx) * cell, cell);
 }
 
 // Level 3 of the binning: the tiles of macro tile (mxs, mys), one per lane.
