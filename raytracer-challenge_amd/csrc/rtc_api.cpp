@@ -262,6 +262,7 @@ void rtc_context_destroy(rtc_context *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_canvas) (void)hipFree(ctx->d_canvas);
+    if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
     for (auto &pair : ctx->ev)
         for (hipEvent_t e : pair)
             if (e) (void)hipEventDestroy(e);
@@ -435,8 +436,7 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
               hipMalloc(&w->d_bound_s, sizeof(DevBound) * na) == hipSuccess &&
               hipMalloc(&w->d_orig_s, sizeof(uint32_t) * na) == hipSuccess &&
               hipMalloc(&w->d_gbound, sizeof(DevBound) * gbound.size()) == hipSuccess &&
-              hipMalloc(&w->d_idtab, sizeof(DevIdEntry) * na) == hipSuccess &&
-              hipMalloc(&w->d_bin_global, sizeof(uint32_t) * RTC_MAX_VIEWS * (RTC_BIN_WIDE_CAP + 1u)) == hipSuccess;
+              hipMalloc(&w->d_idtab, sizeof(DevIdEntry) * na) == hipSuccess;
     for (uint32_t i = 0; i < n; ++i)
         if (!std::isfinite(bound_s[i].r)) w->n_unb = i + 1u; // unbounded objects sort first (key 0)
     ok = ok && hipMemcpy(w->d_isect, isect.data(), sizeof(DevIsect) * na, hipMemcpyHostToDevice) == hipSuccess &&
@@ -449,8 +449,7 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
          hipMemcpy(w->d_orig_s, orig_s.data(), sizeof(uint32_t) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_gbound, gbound.data(), sizeof(DevBound) * gbound.size(), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_idtab, idtab.data(), sizeof(DevIdEntry) * na, hipMemcpyHostToDevice) == hipSuccess &&
-         hipMemset(w->d_prim, 0, sizeof(DevPrim) * na) == hipSuccess &&
-         hipMemset(w->d_bin_global, 0, sizeof(uint32_t) * RTC_MAX_VIEWS * (RTC_BIN_WIDE_CAP + 1u)) == hipSuccess;
+         hipMemset(w->d_prim, 0, sizeof(DevPrim) * na) == hipSuccess;
     // light-space shadow lists (two-level worlds): every shadow segment ends at the light, so the objects a segment can meet
     // are listed per direction cell of a cube map around the light, once per World. Reach = twice the far side of the
     // farthest bounded object as seen from the light (longer segments fall back to the group walk).
@@ -499,11 +498,15 @@ void rtc_world_destroy(rtc_world *w) {
     if (w->d_orig_s) (void)hipFree(w->d_orig_s);
     if (w->d_gbound) (void)hipFree(w->d_gbound);
     if (w->d_idtab) (void)hipFree(w->d_idtab);
-    if (w->d_tile_bundles) (void)hipFree(w->d_tile_bundles);
-    if (w->d_macro_bundles) (void)hipFree(w->d_macro_bundles);
-    if (w->d_tile_cnt) (void)hipFree(w->d_tile_cnt);
-    if (w->d_tile_list) (void)hipFree(w->d_tile_list);
-    if (w->d_bin_global) (void)hipFree(w->d_bin_global);
+    for (rtc_world::BinSet &b : w->bin) {
+        if (b.tile_bundles) (void)hipFree(b.tile_bundles);
+        if (b.macro_bundles) (void)hipFree(b.macro_bundles);
+        if (b.tile_cnt) (void)hipFree(b.tile_cnt);
+        if (b.tile_list) (void)hipFree(b.tile_list);
+        if (b.wide) (void)hipFree(b.wide);
+        if (b.binned) (void)hipEventDestroy(b.binned);
+        if (b.traced) (void)hipEventDestroy(b.traced);
+    }
     if (w->d_light_cells) (void)hipFree(w->d_light_cells);
     if (w->d_light_cnt) (void)hipFree(w->d_light_cnt);
     if (w->d_light_list) (void)hipFree(w->d_light_list);
@@ -548,41 +551,55 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     // binned primary pass (two-level worlds, tile rows aligned with the image's): three small kernels put
     // every object on the list of each 8x8 tile its bounding sphere can touch (same conservative predicate as the wave-level
     // cull), so the render kernel's primary pass runs exact tests on a short list instead of walking the groups
-    // (small worlds, one-level cull: off unless RTC_BIN_SMALL_VIEWS says otherwise — the three extra launches cost about
-    // what a 100-object frame's primary cull saves)
+    // (small worlds, one-level cull: only in launches of several views, where the binning hides behind the previous launch)
     const bool bin_this = (src == SRC_CULL2) || (src == SRC_CULL && nviews >= ctx->bin_small_views);
-    if (bin_this && ctx->binning && (y0 % 8u) == 0u && w->n != 0u && w->d_bin_global) {
+    rtc_world::BinSet *binset = nullptr;
+    if (bin_this && ctx->binning && (y0 % 8u) == 0u && w->n != 0u) {
         const uint32_t tiles_x = (cam->hsize + 7u) / 8u, tiles_y = (cam->vsize + 7u) / 8u;
         const uint32_t macros_x = (tiles_x + 7u) / 8u, macros_y = (tiles_y + 7u) / 8u;
         // macro tiles and super tiles (8x8 macro tiles) share one buffer
         const size_t tiles = (size_t)tiles_x * tiles_y * nviews,
                      macros = ((size_t)macros_x * macros_y + (size_t)((macros_x + 7u) / 8u) * ((macros_y + 7u) / 8u)) * nviews;
-        if (w->bin_tiles_cap < tiles) {
-            if (w->d_tile_bundles) (void)hipFree(w->d_tile_bundles);
-            if (w->d_tile_cnt) (void)hipFree(w->d_tile_cnt);
-            if (w->d_tile_list) (void)hipFree(w->d_tile_list);
-            w->d_tile_bundles = nullptr; w->d_tile_cnt = nullptr; w->d_tile_list = nullptr;
-            w->bin_tiles_cap = 0;
-            HIP_TRY(hipMalloc(&w->d_tile_bundles, sizeof(DevTileBundle) * tiles));
-            HIP_TRY(hipMalloc(&w->d_tile_cnt, sizeof(uint32_t) * tiles));
-            HIP_TRY(hipMalloc(&w->d_tile_list, sizeof(uint32_t) * tiles * RTC_TILE_LIST_CAP));
-            w->bin_tiles_cap = tiles;
+        rtc_world::BinSet &B = w->bin[w->bin_next++ & 1u];
+        if (!ctx->side_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        if (!B.binned) {
+            HIP_TRY(hipEventCreateWithFlags(&B.binned, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&B.traced, hipEventDisableTiming));
+            HIP_TRY(hipMalloc(&B.wide, sizeof(uint32_t) * RTC_MAX_VIEWS * (RTC_BIN_WIDE_CAP + 1u)));
         }
-        if (w->bin_macros_cap < macros) {
-            if (w->d_macro_bundles) (void)hipFree(w->d_macro_bundles);
-            w->d_macro_bundles = nullptr;
-            w->bin_macros_cap = 0;
-            HIP_TRY(hipMalloc(&w->d_macro_bundles, sizeof(DevTileBundle) * macros));
-            w->bin_macros_cap = macros;
+        if (B.tiles_cap < tiles) { // (hipFree waits for the device: nothing reads the old buffers any more)
+            if (B.tile_bundles) (void)hipFree(B.tile_bundles);
+            if (B.tile_cnt) (void)hipFree(B.tile_cnt);
+            if (B.tile_list) (void)hipFree(B.tile_list);
+            B.tile_bundles = nullptr; B.tile_cnt = nullptr; B.tile_list = nullptr;
+            B.tiles_cap = 0;
+            HIP_TRY(hipMalloc(&B.tile_bundles, sizeof(DevTileBundle) * tiles));
+            HIP_TRY(hipMalloc(&B.tile_cnt, sizeof(uint32_t) * tiles));
+            HIP_TRY(hipMalloc(&B.tile_list, sizeof(uint32_t) * tiles * RTC_TILE_LIST_CAP));
+            B.tiles_cap = tiles;
         }
-        HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound, w->d_tile_bundles, w->d_macro_bundles,
-                                   w->d_tile_cnt, w->d_tile_list, w->d_bin_global, ctx->stream));
-        P.tile_cnt = w->d_tile_cnt;
-        P.tile_list = w->d_tile_list;
+        if (B.macros_cap < macros) {
+            if (B.macro_bundles) (void)hipFree(B.macro_bundles);
+            B.macro_bundles = nullptr;
+            B.macros_cap = 0;
+            HIP_TRY(hipMalloc(&B.macro_bundles, sizeof(DevTileBundle) * macros));
+            B.macros_cap = macros;
+        }
+        // The binning depends on the World (resident since rtc_world_create) and on this launch's cameras only, so it goes
+        // to the side stream: it runs beside the PREVIOUS launch's render kernel, which still reads the other set. It must
+        // wait for the render kernel that last read THIS set (two launches ago); the render stream waits for the binning.
+        HIP_TRY(hipStreamWaitEvent(ctx->side_stream, B.traced, 0)); // never recorded: no wait
+        HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound, B.tile_bundles, B.macro_bundles, B.tile_cnt,
+                                   B.tile_list, B.wide, ctx->side_stream));
+        HIP_TRY(hipEventRecord(B.binned, ctx->side_stream));
+        HIP_TRY(hipStreamWaitEvent(ctx->stream, B.binned, 0));
+        P.tile_cnt = B.tile_cnt;
+        P.tile_list = B.tile_list;
         P.tiles_x = tiles_x;
         P.tiles_y = tiles_y;
-        P.bin_wide = w->d_bin_global;
+        P.bin_wide = B.wide;
         P.n_unb = w->n_unb;
+        binset = &B;
     }
     // per-render prologue table of the brute-force variants (the culled kernels do not use it)
     if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.views[0].vinv, ctx->stream));
@@ -601,6 +618,7 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     hipEvent_t *pair = ctx->ev[slot];
     HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y * nviews, lds_bytes, ctx->stream,
                              timed ? pair[0] : nullptr, timed ? pair[1] : nullptr));
+    if (binset) HIP_TRY(hipEventRecord(binset->traced, ctx->stream));
     ++ctx->launches;
     if (timed) ++ctx->timed;
     return RTC_OK;

@@ -30,14 +30,15 @@ struct rtc_context {
     size_t canvas_bytes = 0;
     int force_src = -1;   // RTC_SRC env override (experiments)
     uint32_t tile_cap = 512;
+    hipStream_t side_stream = nullptr; // created on demand: per-render binning kernels run here, beside the previous launch's render
     bool light_lists = true; // RTC_LIGHT_LISTS=0: shadow passes of two-level worlds walk the groups (A/B)
     bool binning = true;  // RTC_BINNING=0: primary rays take the wave-level cull / group walk too (A/B)
-    // one-level worlds (<= 256 objects) are binned only in launches of at least this many views (RTC_BIN_SMALL_VIEWS). Off by
-    // default: measured on one box with 8 views per launch the render kernel gains 12 % (north star 0.0748 -> 0.0660 ms) but
-    // the three extra launches take most of it back (wall 0.0757 -> 0.0732), C2 loses (0.0617 -> 0.0644), C4 gains 3 %.
-    // A single-launch form that computes the cones on the fly (no tables) was tried as well: the kernel gains the same
-    // 13 % and the launch costs the same 9 us per frame (profiles/r02_exp_binned_small_worlds.log)
-    uint32_t bin_small_views = 0xffffffffu;
+    // one-level worlds (<= 256 objects) are binned only in launches of at least this many views (RTC_BIN_SMALL_VIEWS): the
+    // binning kernels run on the side stream beside the previous launch's render, which hides them when launches follow each
+    // other (north star, 8 views per launch: 0.0745 -> 0.0685 ms per frame; 4 views: 0.0732 -> 0.0704; C4 1.48 -> 1.42;
+    // C2 unchanged) but not in front of a lone one-view launch (0.0824 -> 0.0895). Before the side stream the same binning
+    // gave the render kernel its 12 % and took it all back in launch latency (profiles/r02_exp_binned_small_worlds.log).
+    uint32_t bin_small_views = 4;
 };
 
 struct rtc_world {
@@ -55,16 +56,23 @@ struct rtc_world {
     uint32_t *d_orig_s = nullptr;
     DevBound *d_gbound = nullptr;
     DevIdEntry *d_idtab = nullptr;
-    // binned primary pass (two-level worlds): per-render scratch, grow-only (rtc_render_* take the World as const: mutable)
-    mutable DevTileBundle *d_tile_bundles = nullptr, *d_macro_bundles = nullptr;
-    mutable uint32_t *d_tile_cnt = nullptr, *d_tile_list = nullptr;
-    uint32_t *d_bin_global = nullptr; // [RTC_MAX_VIEWS][1 + RTC_BIN_WIDE_CAP]: deferred wide objects per view
+    // binned primary pass: per-render scratch, grow-only, TWO sets — the binning of launch k+1 runs on the context's side
+    // stream while launch k's render kernel still reads set k (rtc_render_* take the World as const: mutable)
+    struct BinSet {
+        DevTileBundle *tile_bundles = nullptr, *macro_bundles = nullptr;
+        uint32_t *tile_cnt = nullptr, *tile_list = nullptr;
+        uint32_t *wide = nullptr;        // [RTC_MAX_VIEWS][1 + RTC_BIN_WIDE_CAP]: deferred wide objects per view
+        size_t tiles_cap = 0, macros_cap = 0; // capacity in (view, tile) / (view, macro tile) entries
+        hipEvent_t binned = nullptr;     // recorded on the side stream after the set's binning kernels
+        hipEvent_t traced = nullptr;     // recorded on the render stream after the render kernel that read the set
+    };
+    mutable BinSet bin[2];
+    mutable uint32_t bin_next = 0;
     // light-space shadow lists (two-level worlds), built once at rtc_world_create
     DevTileBundle *d_light_cells = nullptr;
     uint32_t *d_light_cnt = nullptr, *d_light_list = nullptr;
     double light_reach = 0.;
     uint32_t n_unb = 0;               // unbounded objects: the first n_unb entries of the Morton-sorted tables
-    mutable size_t bin_tiles_cap = 0, bin_macros_cap = 0; // capacity in (view, tile) / (view, macro tile) entries
     uint32_t ngroups = 0;
     rtc_light light{};
     bool any_refl = false, any_refr = false;
