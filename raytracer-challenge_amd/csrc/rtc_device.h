@@ -78,7 +78,8 @@ struct DevTileBundle {
 // every group sphere of the World. Cells whose list overflows, segments longer than light_reach and unbounded objects fall
 // back to the walk / are tested always.
 #define RTC_LIGHT_R 128u
-#define RTC_LIGHT_LIST_CAP 128u
+#define RTC_LIGHT_LIST_CAP 128u      // entries per cell, two-level worlds (filtered 64 at a time)
+#define RTC_LIGHT_LIST_CAP_SMALL 16u // one-level worlds: the lists are the candidates themselves
 
 // Rounding note. The cull must never drop an object for which the REFERENCE ARITHMETIC reports an
 // intersection — including intersections that exist only because of rounding. The sphere test
@@ -151,6 +152,7 @@ struct RenderParams {
     // light-space shadow lists (nullptr: none): per direction cell a counter and RTC_LIGHT_LIST_CAP insertion indices
     const uint32_t *light_cnt;
     const uint32_t *light_list;
+    uint32_t light_cap;          // entries per cell of THIS World's lists
     double light_reach;
     const uint32_t *bin_wide;   // per view: [0] number of deferred wide objects (> RTC_BIN_WIDE_CAP: the lists are incomplete)
     uint32_t n_unb;             // unbounded objects = the first n_unb entries of isect_s / kind_s / orig_s

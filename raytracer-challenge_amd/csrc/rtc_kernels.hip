@@ -1364,9 +1364,54 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             c_shadow += popc64(ballot(hit));
             Bundle Bs{};
             Bs.off = true;
+            // Light-space shadow lists, small worlds (one-level cull): the cells' lists are a handful of objects, so they
+            // are the candidates themselves — no shadow bundle, no bound tests: per listed object (each once: a 256-bit
+            // wave-uniform "done" set, cells next to each other list the same objects) the per-lane prefilter and the
+            // exact test.
+            bool listed = false;
+            if constexpr (SRC == SRC_CULL) {
+                const auto &Pl = KP(P_arg);
+                if (Pl.light_cnt != nullptr && ballot(hit) != 0ull && ballot(hit && !(sdist <= Pl.light_reach)) == 0ull) {
+                    const uint32_t cid = hit ? light_cell(vneg(sdir)) : 0u;
+                    listed = true;
+                    uint32_t ncells = 0;
+                    for (unsigned long long todo = ballot(hit); todo;) {
+                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cid, (int)__builtin_ctzll(todo));
+                        todo &= ~ballot(hit && cid == c);
+                        // a cell whose list overflowed is incomplete; hit points scattered over many cells (shadow rays of
+                        // secondary hits) are served better by the bundle cull: fall back
+                        if (Pl.light_cnt[c] > Pl.light_cap || ++ncells > 4u) { listed = false; break; }
+                    }
+                    if (listed) {
+                        for (uint32_t k = 0; k < Pl.n_unb && ballot(sh_pending) != 0ull; ++k) { // unbounded objects: never listed
+                            DIAG(5, 1u);
+                            if (sh_pending && occludes_world(T.kind_s[k], T.isect_s[k].m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
+                        }
+                        unsigned long long done[4] = {0ull, 0ull, 0ull, 0ull}; // one bit per object (n <= 256 in this variant)
+                        for (unsigned long long todo = ballot(hit); todo && ballot(sh_pending) != 0ull;) {
+                            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cid, (int)__builtin_ctzll(todo));
+                            todo &= ~ballot(hit && cid == c);
+                            const uint32_t nl = Pl.light_cnt[c];
+                            const uint32_t *ll = Pl.light_list + (size_t)c * Pl.light_cap;
+                            for (uint32_t e = 0; e < nl; ++e) {
+                                const uint32_t j = ll[e];
+                                const unsigned long long bit = 1ull << (j & 63u);
+                                unsigned long long &word = done[(j >> 6) & 3u];
+                                if (word & bit) continue;
+                                word |= bit;
+                                DIAG_FILTER(DIAG_PTR(7));
+                                if (ballot(sh_pending && ray_touches(over, sdir, T.bound[j])) == 0ull) continue;
+                                DIAG(5, 1u);
+                                if (sh_pending && occludes_world(T.kind[j], T.isect[j].m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
+                                if (ballot(sh_pending) == 0ull) break;
+                            }
+                        }
+                    }
+                }
+            }
             if constexpr (IS_CULL(SRC)) {
                 // the segment over_point -> light, walked from the light: apex = light (shared)
-                if (ballot(hit) != 0ull) Bs = make_bundle<true, true>(hit, lightp, lightp, vneg(sdir), sdist);
+                if (ballot(hit) != 0ull && !listed) Bs = make_bundle<true, true>(hit, lightp, lightp, vneg(sdir), sdist);
 #ifdef RTC_NO_SHADOW_CULL
                 Bs.off = true;
 #endif
@@ -1376,7 +1421,6 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             DIAG(4, (ballot(hit) != 0ull && Bs.off) ? 1u : 0u);
             // Light-space shadow lists (two-level worlds): instead of walking every group sphere, filter the lists of the
             // direction cells (around the light) this wave's segments fall in with the wave's own shadow bundle.
-            bool listed = false;
             if constexpr (SRC == SRC_CULL2) {
                 const auto &Pl = KP(P_arg);
                 if (Pl.light_cnt != nullptr && !Bs.off && Bs.tmax <= Pl.light_reach && ballot(hit) != 0ull) {
@@ -1385,7 +1429,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     for (unsigned long long todo = ballot(hit); todo;) { // a cell whose list overflowed is incomplete: walk instead
                         const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cid, (int)__builtin_ctzll(todo));
                         todo &= ~ballot(hit && cid == c);
-                        if (Pl.light_cnt[c] > RTC_LIGHT_LIST_CAP) { listed = false; break; }
+                        if (Pl.light_cnt[c] > Pl.light_cap) { listed = false; break; }
                     }
                     if (listed) {
                         for (uint32_t k = 0; k < Pl.n_unb && ballot(sh_pending) != 0ull; ++k) { // unbounded objects: never listed
@@ -1396,7 +1440,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                             const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cid, (int)__builtin_ctzll(todo));
                             todo &= ~ballot(hit && cid == c);
                             const uint32_t nl = Pl.light_cnt[c];
-                            const uint32_t *ll = Pl.light_list + (size_t)c * RTC_LIGHT_LIST_CAP;
+                            const uint32_t *ll = Pl.light_list + (size_t)c * Pl.light_cap;
                             for (uint32_t base = 0; base < nl && ballot(sh_pending) != 0ull; base += 64u) {
                                 const uint32_t e = base + lane;
                                 uint32_t idx = 0u;
@@ -2046,7 +2090,7 @@ DEVI Bundle light_bundle_of(const DevTileBundle &t, V3 apex, double reach) { // 
     return B;
 }
 // One wave per object: macro cells (8x8 cells) 64 per step, then the cells of the touched macro cells.
-__global__ void __launch_bounds__(64) k_light_bin(uint32_t n, const DevBound *__restrict__ bound, double lx, double ly, double lz, double reach,
+__global__ void __launch_bounds__(64) k_light_bin(uint32_t n, uint32_t cap, const DevBound *__restrict__ bound, double lx, double ly, double lz, double reach,
                                                    const DevTileBundle *__restrict__ cells, const DevTileBundle *__restrict__ macros,
                                                    uint32_t *__restrict__ cnt, uint32_t *__restrict__ list) {
     constexpr uint32_t R = RTC_LIGHT_R, M = RTC_LIGHT_R / 8u;
@@ -2067,17 +2111,17 @@ __global__ void __launch_bounds__(64) k_light_bin(uint32_t n, const DevBound *__
             const uint32_t cell = (face * R + my * 8u + (lane >> 3)) * R + mx * 8u + (lane & 7u);
             if (bundle_touches(light_bundle_of(cells[cell], o, reach), b)) {
                 const uint32_t slot = atomicAdd(cnt + cell, 1u);
-                if (slot < RTC_LIGHT_LIST_CAP) list[(size_t)cell * RTC_LIGHT_LIST_CAP + slot] = j;
+                if (slot < cap) list[(size_t)cell * cap + slot] = j;
             }
         }
     }
 }
 
-extern "C" hipError_t rtc_launch_light_lists(uint32_t n, const DevBound *bound, const double light[3], double reach, DevTileBundle *cells,
+extern "C" hipError_t rtc_launch_light_lists(uint32_t n, uint32_t cap, const DevBound *bound, const double light[3], double reach, DevTileBundle *cells,
                                              DevTileBundle *macros, uint32_t *cnt, uint32_t *list, hipStream_t stream) {
     constexpr uint32_t R = RTC_LIGHT_R, M = RTC_LIGHT_R / 8u;
     hipLaunchKernelGGL(k_light_cells, dim3((6u * R * R + 6u * M * M + 255u) / 256u), dim3(256), 0, stream, cells, macros, cnt);
-    if (n) hipLaunchKernelGGL(k_light_bin, dim3(n), dim3(64), 0, stream, n, bound, light[0], light[1], light[2], reach, (const DevTileBundle *)cells,
+    if (n) hipLaunchKernelGGL(k_light_bin, dim3(n), dim3(64), 0, stream, n, cap, bound, light[0], light[1], light[2], reach, (const DevTileBundle *)cells,
                               (const DevTileBundle *)macros, cnt, list);
     return hipGetLastError();
 }
