@@ -555,7 +555,8 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     // every object on the list of each 8x8 tile its bounding sphere can touch (same conservative predicate as the wave-level
     // cull), so the render kernel's primary pass runs exact tests on a short list instead of walking the groups
     // (small worlds, one-level cull: only in launches of several views, where the binning hides behind the previous launch)
-    const bool bin_this = (src == SRC_CULL2) || (src == SRC_CULL && nviews >= ctx->bin_small_views);
+    // (and only for whole frames: one rank's share of a 100-object frame renders faster than the frame's binning)
+    const bool bin_this = (src == SRC_CULL2) || (src == SRC_CULL && nviews >= ctx->bin_small_views && band_stride == 1u && y0 == 0u && y1 == cam->vsize);
     rtc_world::BinSet *binset = nullptr;
     if (bin_this && ctx->binning && (y0 % 8u) == 0u && w->n != 0u) {
         const uint32_t tiles_x = (cam->hsize + 7u) / 8u, tiles_y = (cam->vsize + 7u) / 8u;
@@ -593,7 +594,7 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
         // wait for the render kernel that last read THIS set (two launches ago); the render stream waits for the binning.
         HIP_TRY(hipStreamWaitEvent(ctx->side_stream, B.traced, 0)); // never recorded: no wait
         HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound, B.tile_bundles, B.macro_bundles, B.tile_cnt,
-                                   B.tile_list, B.wide, ctx->side_stream));
+                                   B.tile_list, B.wide, y0 / 8u, band_stride, ctx->side_stream));
         HIP_TRY(hipEventRecord(B.binned, ctx->side_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, B.binned, 0));
         P.tile_cnt = B.tile_cnt;

@@ -82,7 +82,7 @@ struct rtc_world {
 
 extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound,
                                          DevTileBundle *tile_bundles, DevTileBundle *macro_bundles, uint32_t *cnt, uint32_t *list,
-                                         uint32_t *wide, hipStream_t stream);
+                                         uint32_t *wide, uint32_t row0, uint32_t row_stride, hipStream_t stream);
 extern "C" hipError_t rtc_launch_light_lists(uint32_t n, uint32_t cap, const DevBound *bound, const double light[3], double reach, DevTileBundle *cells,
                                              DevTileBundle *macros, uint32_t *cnt, uint32_t *list, hipStream_t stream);
 extern "C" hipError_t rtc_launch_undeal(const void *staging, void *canvas, uint32_t nranks, uint32_t nframes, uint32_t H,

@@ -1846,6 +1846,7 @@ struct BinParams {
     DevCamera views[RTC_MAX_VIEWS];
     uint32_t nviews, W, H, n;
     uint32_t tiles_x, tiles_y, macros_x, macros_y, supers_x, supers_y; // 8x8 pixels, 8x8 tiles, 8x8 macro tiles
+    uint32_t row0, row_stride; // the launch renders tile rows row0, row0 + row_stride, ... only (one rank's bands): the others get no lists
 };
 
 DEVI Bundle bundle_of(const DevTileBundle &t, V3 apex) { // a stored cone as the Bundle bundle_touches takes (rho 0, no reach)
@@ -1925,7 +1926,7 @@ __global__ void __launch_bounds__(256) k_cell_bundles(const BinParams Q, DevTile
 DEVI void bin_tiles_of_macro(const BinParams &Q, uint32_t view, uint32_t mxs, uint32_t mys, uint32_t lane, V3 o, const DevBound &b, uint32_t j,
                              const DevTileBundle *__restrict__ tb, uint32_t *__restrict__ cnt, uint32_t *__restrict__ list) {
     const uint32_t tx = mxs * 8u + (lane & 7u), ty = mys * 8u + (lane >> 3);
-    if (tx < Q.tiles_x && ty < Q.tiles_y) {
+    if (tx < Q.tiles_x && ty < Q.tiles_y && ty >= Q.row0 && (ty - Q.row0) % Q.row_stride == 0u) {
         const size_t tile = (size_t)(view * Q.tiles_y + ty) * Q.tiles_x + tx;
         if (bundle_touches(bundle_of(tb[tile], o), b)) {
             const uint32_t slot = atomicAdd(cnt + tile, 1u);
@@ -2020,8 +2021,9 @@ __global__ void __launch_bounds__(64) k_bin_wide(const BinParams Q, const DevBou
 
 extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound,
                                          DevTileBundle *tile_bundles, DevTileBundle *macro_bundles, uint32_t *cnt, uint32_t *list,
-                                         uint32_t *wide, hipStream_t stream) {
+                                         uint32_t *wide, uint32_t row0, uint32_t row_stride, hipStream_t stream) {
     BinParams Q;
+    Q.row0 = row0; Q.row_stride = row_stride ? row_stride : 1u;
     for (uint32_t v = 0; v < nviews; ++v) Q.views[v] = views[v];
     for (uint32_t v = nviews; v < RTC_MAX_VIEWS; ++v) Q.views[v] = views[0];
     Q.nviews = nviews; Q.W = W; Q.H = H; Q.n = n;
