@@ -539,7 +539,8 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     int src;
     size_t lds_bytes;
     choose_source(ctx, w->n, flags, &src, &P.tile_cap, &lds_bytes);
-    const bool cull = src == SRC_CULL || src == SRC_CULL2, refl = w->any_refl || w->any_refr;
+    const int cull = src == SRC_CULL2 ? 2 : src == SRC_CULL ? 1 : 0; // RTC_BLOCK_FOR's cull level
+    const bool refl = w->any_refl || w->any_refr;
     const uint32_t block = RTC_BLOCK_FOR(cull, refl, w->any_refr, false), tile_w = RTC_TILE_W_FOR(cull, refl, w->any_refr, false);
     P.grid_x = (cam->hsize + tile_w - 1u) / tile_w;
     P.grid_y = grid_y;
@@ -834,13 +835,13 @@ rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays
         P.nrays = n;
         P.remaining = remaining;
         P.hits = d_hits;
-        const uint32_t blk = RTC_BLOCK_FOR(true, w->any_refl || w->any_refr, w->any_refr, true);
-        P.grid_x = (n + blk - 1u) / blk;
-        P.grid_y = 1;
-        P.band_stride = 1;
         int src;
         size_t lds_bytes;
         choose_source(ctx, w->n, flags, &src, &P.tile_cap, &lds_bytes);
+        const uint32_t blk = RTC_BLOCK_FOR(src == SRC_CULL2 ? 2 : src == SRC_CULL ? 1 : 0, w->any_refl || w->any_refr, w->any_refr, true);
+        P.grid_x = (n + blk - 1u) / blk;
+        P.grid_y = 1;
+        P.band_stride = 1;
         P.flags = flags;
         if (rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x, lds_bytes, ctx->stream, nullptr,
                              nullptr) != hipSuccess)

@@ -127,8 +127,13 @@ enum { RTC_MAX_VIEWS = 8 };
 #define RTC_COMPACT 0
 #endif
 #define RTC_COMPACT_FOR(cull, refl, refr, probe) (RTC_COMPACT && (cull) && (refl) && !(refr) && !(probe))
+// `cull` is the cull level of the variant: 0 = none, 1 = one level (n <= 256), 2 = two levels (RTC_CULL_LEVEL).
+#ifndef RTC_BLOCK_CULL2
+#define RTC_BLOCK_CULL2 64 // large worlds, flat kernel: C3 0.106 -> 0.102 ms against 128 (profiles/r02_exp_block_size.log)
+#endif
 #define RTC_BLOCK_FOR(cull, refl, refr, probe) \
-    (((refl) || (refr)) ? (RTC_COMPACT_FOR(cull, refl, refr, probe) ? 128 : RTC_BLOCK_STACK) : RTC_BLOCK)
+    (((refl) || (refr)) ? (RTC_COMPACT_FOR(cull, refl, refr, probe) ? 128 : RTC_BLOCK_STACK) \
+                        : ((cull) == 2 && !(probe) ? RTC_BLOCK_CULL2 : RTC_BLOCK))
 #define RTC_TILE_W_FOR(cull, refl, refr, probe) ((RTC_BLOCK_FOR(cull, refl, refr, probe) / 64u) * 8u)
 
 struct RenderParams {

@@ -103,6 +103,7 @@
 
 enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2, SRC_CULL = 3, SRC_CULL2 = 4 };
 #define IS_CULL(S) ((S) == SRC_CULL || (S) == SRC_CULL2)
+#define CULL_LEVEL(S) ((S) == SRC_CULL2 ? 2 : (S) == SRC_CULL ? 1 : 0)
 
 struct V3 {
     double x, y, z;
@@ -958,13 +959,13 @@ DEVI V3 combine(V3 surface, V3 reflected, V3 refracted, bool schlick, double R) 
 // PROBE = true is the rtc_color_at flavour (arbitrary rays in, colours + hit records out); the
 // render flavour (PROBE = false) never carries the hit record's extra vectors in registers.
 template <int SRC, bool REFL, bool REFR, bool PROBE>
-__global__ void __launch_bounds__(RTC_BLOCK_FOR(IS_CULL(SRC), REFL, REFR, PROBE), (REFL ? RTC_WAVES_PER_SIMD_STACK : RTC_WAVES_PER_SIMD))
+__global__ void __launch_bounds__(RTC_BLOCK_FOR(CULL_LEVEL(SRC), REFL, REFR, PROBE), (REFL ? RTC_WAVES_PER_SIMD_STACK : RTC_WAVES_PER_SIMD))
 k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const uint32_t *__restrict__ t_kind,
         const DevShade *__restrict__ t_shade, const DevPrim *__restrict__ t_prim, const DevBound *__restrict__ t_bound,
         const DevIsect *__restrict__ t_isect_s, const uint32_t *__restrict__ t_kind_s, const DevBound *__restrict__ t_bound_s,
         const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound, const DevIdEntry *__restrict__ t_idtab) {
-    constexpr uint32_t BLOCK = RTC_BLOCK_FOR(IS_CULL(SRC), REFL, REFR, PROBE), TILE_W = RTC_TILE_W_FOR(IS_CULL(SRC), REFL, REFR, PROBE);
-    constexpr bool COMPACT = RTC_COMPACT_FOR(IS_CULL(SRC), REFL, REFR, PROBE); // K3: two waves, live rays merged between bounces
+    constexpr uint32_t BLOCK = RTC_BLOCK_FOR(CULL_LEVEL(SRC), REFL, REFR, PROBE), TILE_W = RTC_TILE_W_FOR(CULL_LEVEL(SRC), REFL, REFR, PROBE);
+    constexpr bool COMPACT = RTC_COMPACT_FOR(CULL_LEVEL(SRC), REFL, REFR, PROBE); // K3: two waves, live rays merged between bounces
     extern __shared__ double lds_raw[];
     constexpr bool LDS_STACK = RTC_LDS_STACK && REFL && !REFR; // 32-byte frames in LDS (one wave per workgroup)
     static_assert(!LDS_STACK || BLOCK == 64 || COMPACT, "the tile is staged over the LDS frame stack: one wave per workgroup, or a barrier first");
@@ -1758,13 +1759,15 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 }
                 if (want8) {
                     const size_t row8 = (size_t)Po.W * 3u;
-                    const bool wide8 = cols == TILE_W && (row8 % 16u) == 0 && ((size_t)Po.out8 % 16u) == 0;
+                    // a tile row is 24 bytes per wave: 16-byte pieces for an even number of waves, 8-byte pieces for one
+                    constexpr uint32_t PIECE = (TILE_W * 3u) % 16u == 0 ? 16u : 8u;
+                    const bool wide8 = cols == TILE_W && (row8 % PIECE) == 0 && ((size_t)Po.out8 % PIECE) == 0;
                     if (wide8) {
-                        typedef unsigned __attribute__((ext_vector_type(4))) u4;
-                        for (uint32_t c = threadIdx.x; c < rows * (TILE_W * 3u / 16u); c += BLOCK) {
-                            const uint32_t r = c / (TILE_W * 3u / 16u), k = c % (TILE_W * 3u / 16u);
-                            const u4 v = *reinterpret_cast<const u4 *>(stage_u8 + r * (TILE_W * 3u) + k * 16u);
-                            *reinterpret_cast<u4 *>(Po.out8 + (size_t)(orow0 + r) * row8 + (size_t)px0 * 3u + k * 16u) = v;
+                        typedef unsigned __attribute__((ext_vector_type(PIECE / 4u))) piece_t;
+                        for (uint32_t c = threadIdx.x; c < rows * (TILE_W * 3u / PIECE); c += BLOCK) {
+                            const uint32_t r = c / (TILE_W * 3u / PIECE), k = c % (TILE_W * 3u / PIECE);
+                            const piece_t v = *reinterpret_cast<const piece_t *>(stage_u8 + r * (TILE_W * 3u) + k * PIECE);
+                            *reinterpret_cast<piece_t *>(Po.out8 + (size_t)(orow0 + r) * row8 + (size_t)px0 * 3u + k * PIECE) = v;
                         }
                     } else {
                         for (uint32_t c = threadIdx.x; c < rows * cols * 3u; c += BLOCK) {
@@ -2173,7 +2176,7 @@ static hipError_t launch_kernel(const RenderParams &P, dim3 grid, size_t lds_byt
         if (e != hipSuccess) return e;
     }
     // e0/e1 (may be NULL) receive the dispatch's own begin/end timestamps: no marker packets on the stream
-    hipExtLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK_FOR(IS_CULL(SRC), REFL, REFR, PROBE)), lds_bytes, stream, e0, e1, 0, P, P.isect,
+    hipExtLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK_FOR(CULL_LEVEL(SRC), REFL, REFR, PROBE)), lds_bytes, stream, e0, e1, 0, P, P.isect,
                           P.kind, P.shade, P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound, P.idtab);
     return hipGetLastError();
 }
