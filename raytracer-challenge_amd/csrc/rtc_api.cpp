@@ -603,6 +603,7 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
         P.tiles_x = tiles_x;
         P.tiles_y = tiles_y;
         P.bin_wide = B.wide;
+        P.bin_packed = RTC_BIN_PACKED(w->n) ? 1u : 0u;
         P.n_unb = w->n_unb;
         binset = &B;
     }

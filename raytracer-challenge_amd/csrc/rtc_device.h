@@ -136,6 +136,9 @@ enum { RTC_MAX_VIEWS = 8 };
                         : ((cull) == 2 && !(probe) ? RTC_BLOCK_CULL2 : RTC_BLOCK))
 #define RTC_TILE_W_FOR(cull, refl, refr, probe) ((RTC_BLOCK_FOR(cull, refl, refr, probe) / 64u) * 8u)
 
+// Tile-list entries hold (key >> 16) << 16 | index while every index fits 16 bits
+#define RTC_BIN_PACKED(n) ((n) <= 65536u)
+
 struct RenderParams {
     const DevIsect *isect;
     const uint32_t *kind;
@@ -159,6 +162,7 @@ struct RenderParams {
     const uint32_t *light_list;
     uint32_t light_cap;          // entries per cell of THIS World's lists
     double light_reach;
+    uint32_t bin_packed;        // tile-list entries carry the upper half of the object's key above its index (RTC_BIN_PACKED)
     const uint32_t *bin_wide;   // per view: [0] number of deferred wide objects (> RTC_BIN_WIDE_CAP: the lists are incomplete)
     uint32_t n_unb;             // unbounded objects = the first n_unb entries of isect_s / kind_s / orig_s
     uint32_t ngroups;

@@ -46,6 +46,12 @@
 // barrier + cooperative store of the workgroup's whole tile (full 128-byte lines). Measured: the barrier
 // form wins for the flat kernel (0.0738 vs 0.0784 ms, 192-byte row pieces straddle lines), the
 // per-wave form for the frame-stack kernels, whose waves finish far apart (0.662 vs 0.690 ms).
+// Binned primary pass: request the tile's list at kernel entry, ahead of the ray generation (1), or where the pass needs
+// it (0). Measured: the early request is SLOWER (north star +3 %, C5 +4 %, where it also reads all 64 slots of a million
+// tiles; profiles/r02_exp_packed_tile_lists.log), so it is off.
+#ifndef RTC_BIN_HOIST
+#define RTC_BIN_HOIST 0
+#endif
 #ifndef RTC_WAVE_OUTPUT
 #define RTC_WAVE_OUTPUT(REFL) (REFL)
 #endif
@@ -1034,6 +1040,34 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
 #endif
     STAMP(0);
 
+    // Binned primary pass: this wave's 8x8 tile has a list of the objects its primary rays can touch (k_bin_objects /
+    // k_bin_wide): lane e holds entry e. (RTC_BIN_HOIST: the 64 entry slots of a tile always exist, the ones past the
+    // count hold garbage and are masked in the walk.)
+    bool binned = false;
+    uint32_t bin_cnt = 0, bin_ent = 0xffffffffu;
+    auto tile_lookup = [&]() {
+        const auto &Pt = KP(P_arg);
+        if (Pt.tile_cnt != nullptr) {
+            const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave); // wave-uniform by construction
+            const uint32_t itx = (tbid % Pt.grid_x) * (TILE_W / 8u) + wv, ity = (Pt.y0 >> 3) + (tbid / Pt.grid_x) * Pt.band_stride;
+            if (itx < Pt.tiles_x && ity < Pt.tiles_y) {
+                const size_t tile = (size_t)(view * Pt.tiles_y + ity) * Pt.tiles_x + itx;
+#if RTC_BIN_HOIST
+                bin_ent = Pt.tile_list[tile * RTC_TILE_LIST_CAP + lane];
+                bin_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)Pt.tile_cnt[tile]);
+#else
+                bin_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)Pt.tile_cnt[tile]);
+                if (lane < bin_cnt) bin_ent = Pt.tile_list[tile * RTC_TILE_LIST_CAP + lane];
+#endif
+                // an overflowing list (the tile's, or the view's list of deferred wide objects) is incomplete: walk instead
+                binned = bin_cnt <= RTC_TILE_LIST_CAP && Pt.bin_wide[(size_t)view * (RTC_BIN_WIDE_CAP + 1u)] <= RTC_BIN_WIDE_CAP;
+            }
+        }
+    };
+#if RTC_BIN_HOIST
+    if constexpr (IS_CULL(SRC) && !PROBE) tile_lookup();
+#endif
+
     // render_pixel (camera.rs:94-114): one ray, or the 4 fixed sub-samples followed — for the pixels whose
     // samples differ by more than 0.01 from their mean — by `resample_n` more rays (Camera::resample)
     const bool aa = !probe && P.samples != 1u;
@@ -1154,28 +1188,14 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             int hidx = -1, hroot = 0;
             Bundle B{}; // every field defined: an undefined field turns into a value carried around the pass loop
             B.off = true;
-            // binned primary pass: this wave's 8x8 tile has a list of the objects its primary rays can touch
-            bool binned = false;
-            uint32_t bin_cnt = 0;
-            const uint32_t *bin_list = nullptr;
+#if !RTC_BIN_HOIST
             if constexpr (IS_CULL(SRC) && !PROBE) {
-                if (shared_origin && first) {
-                    const auto &Pt = KP(P_arg);
-                    if (Pt.tile_cnt != nullptr) {
-                        const uint32_t wv = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave); // wave-uniform by construction
-                        const uint32_t itx = (tbid % Pt.grid_x) * (TILE_W / 8u) + wv, ity = (Pt.y0 >> 3) + (tbid / Pt.grid_x) * Pt.band_stride;
-                        if (itx < Pt.tiles_x && ity < Pt.tiles_y) {
-                            const size_t tile = (size_t)(view * Pt.tiles_y + ity) * Pt.tiles_x + itx;
-                            bin_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)Pt.tile_cnt[tile]);
-                            bin_list = Pt.tile_list + tile * RTC_TILE_LIST_CAP;
-                            // an overflowing list (the tile's, or the view's list of deferred wide objects) is incomplete: walk instead
-                            binned = bin_cnt <= RTC_TILE_LIST_CAP && Pt.bin_wide[(size_t)view * (RTC_BIN_WIDE_CAP + 1u)] <= RTC_BIN_WIDE_CAP;
-                        }
-                    }
-                }
+                if (shared_origin && first) tile_lookup();
             }
+#endif
+            const bool use_bins = binned && shared_origin && first; // (binned is false in the probe and brute-force variants)
             if constexpr (IS_CULL(SRC)) {
-                if (ballot(tracing) != 0ull && !binned) {
+                if (ballot(tracing) != 0ull && !use_bins) {
                     if (shared_origin && first) B = make_bundle<true, false>(tracing, cam_origin, ro, rd, 0.);
                     else B = make_bundle<false, false>(tracing, cam_origin, ro, rd, 0.);
 #ifdef RTC_NO_SECONDARY_CULL
@@ -1204,7 +1224,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     return true;
                 }, ro, rd, NoSkip{}, DIAG_PTR(6), DIAG_PTR(8), DIAG_PTR(10));
 #endif
-            } else if (IS_CULL(SRC) && !PROBE && shared_origin && first && binned) {
+            } else if (IS_CULL(SRC) && !PROBE && use_bins) {
                 // binned primary pass: the unbounded objects, then the tile's own list (k_bin_objects / k_bin_wide) — together
                 // every object this tile's rays can touch
                 const auto &Pb = KP(P_arg);
@@ -1215,20 +1235,36 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 // the tile's list, nearest first: lane e holds entry e and the lower bound of the distance from the camera to
                 // its (inflated) bounding sphere — every intersection of that object has t >= key for these unit-direction
                 // rays — and the walk stops at the first key no lane can use any more (as the ordered group walk does)
-                uint32_t my_j = 0u;
-                float my_key = 0.f;
-                if (lane < bin_cnt) {
-                    my_j = bin_list[lane];
-                    my_key = bound_key(cam_origin, T.bound[my_j]);
-                }
-                unsigned long long lmask = bin_cnt >= 64u ? ~0ull : ((1ull << bin_cnt) - 1ull);
-                while (lmask) {
-                    float kmin;
-                    const int sel = take_min_key(lmask, my_key, kmin);
-                    if (ballot(tracing && !(best < (double)kmin)) == 0ull) break;
-                    const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)my_j, sel);
-                    DIAG(2, 1u);
-                    if (tracing) closest_world(T.kind[j], T.isect[j].m, ro, rd, (int)j, best, hidx, hroot);
+                if (Pb.bin_packed) {
+                    // entry = key's upper 16 bits (truncated: still a lower bound) above the object index: the wave's
+                    // minimum IS the next object and its key
+                    uint32_t ent = lane < bin_cnt ? bin_ent : 0xffffffffu;
+                    for (;;) {
+                        const uint32_t e = ~wave_max_u32(~ent);
+                        if (e == 0xffffffffu) break;
+                        const float kmin = __builtin_bit_cast(float, e & 0xffff0000u);
+                        if (ballot(tracing && !(best < (double)kmin)) == 0ull) break;
+                        if (ent == e) ent = 0xffffffffu;
+                        const uint32_t j = e & 0xffffu;
+                        DIAG(2, 1u);
+                        if (tracing) closest_world(T.kind[j], T.isect[j].m, ro, rd, (int)j, best, hidx, hroot);
+                    }
+                } else { // more than 65 536 objects: plain indices, keys from the bounds
+                    uint32_t my_j = 0u;
+                    float my_key = 0.f;
+                    if (lane < bin_cnt) {
+                        my_j = bin_ent;
+                        my_key = bound_key(cam_origin, T.bound[my_j]);
+                    }
+                    unsigned long long lmask = bin_cnt >= 64u ? ~0ull : ((1ull << bin_cnt) - 1ull);
+                    while (lmask) {
+                        float kmin;
+                        const int sel = take_min_key(lmask, my_key, kmin);
+                        if (ballot(tracing && !(best < (double)kmin)) == 0ull) break;
+                        const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)my_j, sel);
+                        DIAG(2, 1u);
+                        if (tracing) closest_world(T.kind[j], T.isect[j].m, ro, rd, (int)j, best, hidx, hroot);
+                    }
                 }
             } else if (SRC == SRC_CULL2 && !PROBE && shared_origin && first) {
                 // primary rays of a large world: start at the apex, unit direction -> ordered walk with early stop
@@ -1849,6 +1885,7 @@ struct BinParams {
     DevCamera views[RTC_MAX_VIEWS];
     uint32_t nviews, W, H, n;
     uint32_t tiles_x, tiles_y, macros_x, macros_y, supers_x, supers_y; // 8x8 pixels, 8x8 tiles, 8x8 macro tiles
+    uint32_t packed;           // n <= 65 536: list entries carry the key (bin_entry)
     uint32_t row0, row_stride; // the launch renders tile rows row0, row0 + row_stride, ... only (one rank's bands): the others get no lists
 };
 
@@ -1925,15 +1962,22 @@ __global__ void __launch_bounds__(256) k_cell_bundles(const BinParams Q, DevTile
     out[i] = cell_cone(Q, view, (t % gx) * cell, (t / gx) * cell, cell);
 }
 
+// A tile-list entry: the object's index and, while the indices fit 16 bits (BinParams::packed), the upper half of its
+// key above it — bound_key from the view's camera, truncated towards zero (keys are >= 0), so still a lower bound.
+DEVI uint32_t bin_entry(const BinParams &Q, V3 o, const DevBound &b, uint32_t j) {
+    if (!Q.packed) return j;
+    return (__builtin_bit_cast(uint32_t, bound_key(o, b)) & 0xffff0000u) | j;
+}
+
 // Level 3 of the binning: the tiles of macro tile (mxs, mys), one per lane.
-DEVI void bin_tiles_of_macro(const BinParams &Q, uint32_t view, uint32_t mxs, uint32_t mys, uint32_t lane, V3 o, const DevBound &b, uint32_t j,
+DEVI void bin_tiles_of_macro(const BinParams &Q, uint32_t view, uint32_t mxs, uint32_t mys, uint32_t lane, V3 o, const DevBound &b, uint32_t entry,
                              const DevTileBundle *__restrict__ tb, uint32_t *__restrict__ cnt, uint32_t *__restrict__ list) {
     const uint32_t tx = mxs * 8u + (lane & 7u), ty = mys * 8u + (lane >> 3);
     if (tx < Q.tiles_x && ty < Q.tiles_y && ty >= Q.row0 && (ty - Q.row0) % Q.row_stride == 0u) {
         const size_t tile = (size_t)(view * Q.tiles_y + ty) * Q.tiles_x + tx;
         if (bundle_touches(bundle_of(tb[tile], o), b)) {
             const uint32_t slot = atomicAdd(cnt + tile, 1u);
-            if (slot < RTC_TILE_LIST_CAP) list[tile * RTC_TILE_LIST_CAP + slot] = j;
+            if (slot < RTC_TILE_LIST_CAP) list[tile * RTC_TILE_LIST_CAP + slot] = entry;
         }
     }
 }
@@ -1953,6 +1997,7 @@ __global__ void __launch_bounds__(64) k_bin_objects(const BinParams Q, const Dev
     V3 o = xpoint(C.vinv, mk(0., 0., 0.));
     o = mk(uniform_f64(o.x), uniform_f64(o.y), uniform_f64(o.z));
     const uint32_t supers = Q.supers_x * Q.supers_y, macros = Q.macros_x * Q.macros_y;
+    const uint32_t entry = bin_entry(Q, o, b, j);
     for (int pass = 0; pass < 2; ++pass) {
         uint32_t touched = 0;
         for (uint32_t sbase = 0; sbase < supers; sbase += 64u) {
@@ -1982,7 +2027,7 @@ __global__ void __launch_bounds__(64) k_bin_objects(const BinParams Q, const Dev
                 while (mmask) {
                     const uint32_t l = (uint32_t)__builtin_ctzll(mmask);
                     mmask &= mmask - 1ull;
-                    bin_tiles_of_macro(Q, view, (ssel % Q.supers_x) * 8u + (l & 7u), (ssel / Q.supers_x) * 8u + (l >> 3), lane, o, b, j, tb, cnt, list);
+                    bin_tiles_of_macro(Q, view, (ssel % Q.supers_x) * 8u + (l & 7u), (ssel / Q.supers_x) * 8u + (l >> 3), lane, o, b, entry, tb, cnt, list);
                 }
             }
         }
@@ -2014,10 +2059,11 @@ __global__ void __launch_bounds__(64) k_bin_wide(const BinParams Q, const DevBou
         const DevBound b = bound[j];
         if (!bundle_touches(bundle_of(sbun, o), b)) continue;
         unsigned long long mmask = ballot(mvalid && bundle_touches(bundle_of(mbun, o), b));
+        const uint32_t entry = bin_entry(Q, o, b, j);
         while (mmask) {
             const uint32_t l = (uint32_t)__builtin_ctzll(mmask);
             mmask &= mmask - 1ull;
-            bin_tiles_of_macro(Q, view, (ssel % Q.supers_x) * 8u + (l & 7u), (ssel / Q.supers_x) * 8u + (l >> 3), lane, o, b, j, tb, cnt, list);
+            bin_tiles_of_macro(Q, view, (ssel % Q.supers_x) * 8u + (l & 7u), (ssel / Q.supers_x) * 8u + (l >> 3), lane, o, b, entry, tb, cnt, list);
         }
     }
 }
@@ -2030,6 +2076,7 @@ extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews
     for (uint32_t v = 0; v < nviews; ++v) Q.views[v] = views[v];
     for (uint32_t v = nviews; v < RTC_MAX_VIEWS; ++v) Q.views[v] = views[0];
     Q.nviews = nviews; Q.W = W; Q.H = H; Q.n = n;
+    Q.packed = RTC_BIN_PACKED(n) ? 1u : 0u;
     Q.tiles_x = (W + 7u) / 8u; Q.tiles_y = (H + 7u) / 8u;
     Q.macros_x = (Q.tiles_x + 7u) / 8u; Q.macros_y = (Q.tiles_y + 7u) / 8u;
     Q.supers_x = (Q.macros_x + 7u) / 8u; Q.supers_y = (Q.macros_y + 7u) / 8u;

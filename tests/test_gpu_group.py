@@ -288,3 +288,31 @@ def test_binned_primary_pass_and_light_lists_equal_the_group_walk(rtc, O, scenes
         assert np.max(np.abs(a[y, x] - want)) <= TIGHT_TOL, (x, y)
     ctx_bin.close()
     ctx_walk.close()
+
+
+def test_tile_lists_of_worlds_beyond_65536_objects(rtc):
+    """Tile-list entries carry the upper half of the object's key above a 16-bit index (RTC_BIN_PACKED); Worlds with more
+    than 65 536 objects fall back to plain indices and keys computed from the bounds. Both forms must give the walk's and
+    brute force's canvas bit for bit (this one is the fallback; every other binned test runs the packed form). Most of the
+    spheres sit behind the camera so that the tiles' lists stay below their capacity and are actually used."""
+    rng = np.random.default_rng(5)
+    u = lambda a, b: float(rng.uniform(a, b))
+    w = rtc.World(rtc.light((-6.0, 9.0, -8.0)))
+    mat = rtc.material(color=(0.4, 0.7, 0.5), specular=0.3, shininess=40.0)
+    for i in range(70_000):
+        front = i % 16 == 0
+        r = u(0.03, 0.15)
+        z = u(-2, 25) if front else u(-60, -12)
+        w.add_shape(rtc.sphere(rtc.Matrix.identity().scaling(r, r, r).translation(u(-8, 8), u(0, 6), z),
+                               mat if i % 3 else rtc.material(color=(u(0, 1), u(0, 1), u(0, 1)), specular=0.2)))
+    w.add_shape(rtc.plane(rtc.Matrix.identity(), rtc.material(specular=0.0, pattern=("checker", (0.3,) * 3, (0.7,) * 3, None))))
+    cam = rtc.camera(640, 360, 0.8, rtc.Matrix.make_view_transform((0.0, 2.0, -8.0), (0.0, 1.0, 5.0), (0.0, 1.0, 0.0)))
+    ctx_bin, ctx_walk = rtc.Context(0), _ctx_env(rtc, RTC_BINNING=0, RTC_LIGHT_LISTS=0)
+    dwb, dww = ctx_bin.upload(w), ctx_walk.upload(w)
+    a, sa = dwb.render(cam, with_stats=True)
+    b, sb = dww.render(cam, with_stats=True)
+    c, sc = dwb.render(cam, flags=rtc.FLAG_NO_CULL, with_stats=True)
+    assert np.array_equal(a, b) and sa == sb and np.array_equal(a, c) and sa == sc
+    assert sa["rays_shadow"] > 100_000
+    ctx_bin.close()
+    ctx_walk.close()
