@@ -625,6 +625,20 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y * nviews, lds_bytes, ctx->stream,
                              timed ? pair[0] : nullptr, timed ? pair[1] : nullptr));
     if (binset) HIP_TRY(hipEventRecord(binset->traced, ctx->stream));
+    // rtc_stats::pixels is known here (the kernel traces exactly the pixels of this launch's rows; Camera::render leaves the
+    // last row and column alone, camera.rs:120-121): counted on the host, one atomic per wave less
+    {
+        const bool serial = mode == RTC_MODE_RENDER;
+        unsigned long long rows = 0;
+        for (uint32_t k = 0; k < grid_y; ++k) {
+            const unsigned long long py0 = (unsigned long long)y0 + (unsigned long long)k * band_stride * 8u;
+            if (py0 >= y1) break;
+            unsigned long long r = y1 - py0 < 8u ? y1 - py0 : 8u;
+            if (serial && py0 + r == cam->vsize) --r; // the image's last row
+            rows += r;
+        }
+        ctx->pixels += rows * (cam->hsize - (serial ? 1u : 0u)) * nviews;
+    }
     ++ctx->launches;
     if (timed) ++ctx->timed;
     return RTC_OK;
@@ -664,7 +678,7 @@ rtc_status rtc_stats_read(rtc_context *ctx, rtc_stats *out) {
     out->rays_shadow = h[CNT_SHADOW];
     out->rays_reflect = h[CNT_REFLECT];
     out->rays_refract = h[CNT_REFRACT];
-    out->pixels = h[CNT_PIXELS];
+    out->pixels = ctx->pixels; // counted at launch time (render_launch)
     out->pixels_resample = h[CNT_RESAMPLE];
     return RTC_OK;
 }
@@ -688,6 +702,7 @@ rtc_status rtc_stats_reset(rtc_context *ctx) {
     if (!ctx) return RTC_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N * CNT_SLOTS, ctx->stream));
+    ctx->pixels = 0;
     return RTC_OK;
 }
 

@@ -52,6 +52,15 @@
 #ifndef RTC_BIN_HOIST
 #define RTC_BIN_HOIST 0
 #endif
+// Canvas stores (written once, never read by the kernel): plain (0) or non-temporal (1).
+#ifndef RTC_NT_STORE
+#define RTC_NT_STORE 1
+#endif
+#if RTC_NT_STORE
+#define RTC_CANVAS_STORE(p, v) __builtin_nontemporal_store((v), (p))
+#else
+#define RTC_CANVAS_STORE(p, v) (*(p) = (v))
+#endif
 #ifndef RTC_WAVE_OUTPUT
 #define RTC_WAVE_OUTPUT(REFL) (REFL)
 #endif
@@ -1721,6 +1730,9 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                     q[1] = scale255(result.y);
                     q[2] = scale255(result.z);
                 }
+#ifdef RTC_DIAG_NO_STORE
+                if (Po.W == 0xffffffffu) // never true: keeps the code, skips the stores (diagnosis builds only)
+#endif
                 if constexpr (RTC_WAVE_OUTPUT(REFL)) {
                 // Each wave stores its own 8x8 part of the tile (no workgroup barrier: a wave that is
                 // done retires without waiting for the slowest of its three neighbours). Its LDS
@@ -1743,7 +1755,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                         const uint32_t r = c / 12u, k = c % 12u;
                         const d2 v = *reinterpret_cast<const d2 *>(src + r * (TILE_W * 3u) + k * 2u);
                         char *dst = reinterpret_cast<char *>(Po.out) + (size_t)(orow0 + r) * row_bytes + (size_t)px0 * 24u + k * 16u;
-                        *reinterpret_cast<d2 *>(dst) = v;
+                        RTC_CANVAS_STORE(reinterpret_cast<d2 *>(dst), v);
                     }
                 } else {
                     for (uint32_t c = lane; c < rows * cols * 3u; c += 64u) {
@@ -1761,7 +1773,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                         for (uint32_t c = lane; c < rows * 3u; c += 64u) {
                             const uint32_t r = c / 3u, k = c % 3u;
                             const u2 v = *reinterpret_cast<const u2 *>(src8 + r * (TILE_W * 3u) + k * 8u);
-                            *reinterpret_cast<u2 *>(Po.out8 + (size_t)(orow0 + r) * row8 + (size_t)px0 * 3u + k * 8u) = v;
+                            RTC_CANVAS_STORE(reinterpret_cast<u2 *>(Po.out8 + (size_t)(orow0 + r) * row8 + (size_t)px0 * 3u + k * 8u), v);
                         }
                     } else {
                         for (uint32_t c = lane; c < rows * cols * 3u; c += 64u) {
@@ -1785,7 +1797,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                         const uint32_t r = c / (TILE_W * 3u / 2u), k = c % (TILE_W * 3u / 2u);
                         const d2 v = *reinterpret_cast<const d2 *>(stage_f64 + r * (TILE_W * 3u) + k * 2u);
                         char *dst = reinterpret_cast<char *>(Po.out) + (size_t)(orow0 + r) * row_bytes + (size_t)px0 * 24u + k * 16u;
-                        *reinterpret_cast<d2 *>(dst) = v;
+                        RTC_CANVAS_STORE(reinterpret_cast<d2 *>(dst), v);
                     }
                 } else {
                     for (uint32_t c = threadIdx.x; c < rows * cols * 3u; c += BLOCK) {
@@ -1803,7 +1815,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                         for (uint32_t c = threadIdx.x; c < rows * (TILE_W * 3u / PIECE); c += BLOCK) {
                             const uint32_t r = c / (TILE_W * 3u / PIECE), k = c % (TILE_W * 3u / PIECE);
                             const piece_t v = *reinterpret_cast<const piece_t *>(stage_u8 + r * (TILE_W * 3u) + k * PIECE);
-                            *reinterpret_cast<piece_t *>(Po.out8 + (size_t)(orow0 + r) * row8 + (size_t)px0 * 3u + k * PIECE) = v;
+                            RTC_CANVAS_STORE(reinterpret_cast<piece_t *>(Po.out8 + (size_t)(orow0 + r) * row8 + (size_t)px0 * 3u + k * PIECE), v);
                         }
                     } else {
                         for (uint32_t c = threadIdx.x; c < rows * cols * 3u; c += BLOCK) {
@@ -1819,15 +1831,17 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
 
     STAMP(7); // shaded, stored
     const auto &Pc = KP(P_arg);
+#ifdef RTC_DIAG_NO_COUNTERS
+    if (Pc.counters && Pc.W == 0xffffffffu) {
+#else
     if (Pc.counters) {
-        const uint32_t npix = popc64(ballot(traced));
-        if (lane == 0) {
+#endif
+        if (lane == 0) { // (rtc_stats::pixels is counted by the host, render_launch)
             unsigned long long *slot = Pc.counters + (size_t)((blockIdx.x * (BLOCK / 64u) + wave) % CNT_SLOTS) * CNT_N;
             if (c_primary) atomicAdd(slot + CNT_PRIMARY, (unsigned long long)c_primary);
             if (c_shadow) atomicAdd(slot + CNT_SHADOW, (unsigned long long)c_shadow);
             if (c_reflect) atomicAdd(slot + CNT_REFLECT, (unsigned long long)c_reflect);
             if (c_refract) atomicAdd(slot + CNT_REFRACT, (unsigned long long)c_refract);
-            if (npix) atomicAdd(slot + CNT_PIXELS, (unsigned long long)npix);
             if (c_resample) atomicAdd(slot + CNT_RESAMPLE, (unsigned long long)c_resample);
 #ifdef RTC_STAMPS
             for (int i = 0; i < 7; ++i) atomicAdd(slot + CNT_STAMP0 + i, stamp_t[i + 1] - stamp_t[i]);
