@@ -565,31 +565,40 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
         // macro tiles and super tiles (8x8 macro tiles) share one buffer
         const size_t tiles = (size_t)tiles_x * tiles_y * nviews,
                      macros = ((size_t)macros_x * macros_y + (size_t)((macros_x + 7u) / 8u) * ((macros_y + 7u) / 8u)) * nviews;
-        rtc_world::BinSet &B = w->bin[w->bin_next++ & 1u];
         if (!ctx->side_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-        if (!B.binned) {
-            HIP_TRY(hipEventCreateWithFlags(&B.binned, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&B.traced, hipEventDisableTiming));
-            HIP_TRY(hipMalloc(&B.wide, sizeof(uint32_t) * RTC_MAX_VIEWS * (RTC_BIN_WIDE_CAP + 1u)));
+        // Capacity. Both sets are made ready by the FIRST binned launch, and for RTC_MAX_VIEWS views whenever that stays small
+        // (1080p: 69 MB per set; exactly the launch's views otherwise): a launch sequence must not allocate after its first
+        // launch — hipMalloc / hipFree wait for the device, 0.2-3 ms in the middle of a frame sequence (a 5-frame warm-up
+        // launch followed by 8-frame launches did exactly that: 0.09-0.22 ms per frame instead of 0.07).
+        const size_t per_view_bytes = (size_t)tiles_x * tiles_y * (sizeof(DevTileBundle) + sizeof(uint32_t) * (1u + RTC_TILE_LIST_CAP));
+        const uint32_t alloc_views = per_view_bytes <= ((size_t)128 << 20) ? (uint32_t)RTC_MAX_VIEWS : nviews;
+        const size_t tiles_alloc = (size_t)tiles_x * tiles_y * alloc_views, macros_alloc = macros / nviews * alloc_views;
+        for (rtc_world::BinSet &S : w->bin) {
+            if (!S.binned) {
+                HIP_TRY(hipEventCreateWithFlags(&S.binned, hipEventDisableTiming));
+                HIP_TRY(hipEventCreateWithFlags(&S.traced, hipEventDisableTiming));
+                ++ctx->render_allocs; HIP_TRY(hipMalloc(&S.wide, sizeof(uint32_t) * RTC_MAX_VIEWS * (RTC_BIN_WIDE_CAP + 1u)));
+            }
+            if (S.tiles_cap < tiles) { // (hipFree waits for the device: nothing reads the old buffers any more)
+                if (S.tile_bundles) (void)hipFree(S.tile_bundles);
+                if (S.tile_cnt) (void)hipFree(S.tile_cnt);
+                if (S.tile_list) (void)hipFree(S.tile_list);
+                S.tile_bundles = nullptr; S.tile_cnt = nullptr; S.tile_list = nullptr;
+                S.tiles_cap = 0;
+                ++ctx->render_allocs; HIP_TRY(hipMalloc(&S.tile_bundles, sizeof(DevTileBundle) * tiles_alloc));
+                ++ctx->render_allocs; HIP_TRY(hipMalloc(&S.tile_cnt, sizeof(uint32_t) * tiles_alloc));
+                ++ctx->render_allocs; HIP_TRY(hipMalloc(&S.tile_list, sizeof(uint32_t) * tiles_alloc * RTC_TILE_LIST_CAP));
+                S.tiles_cap = tiles_alloc;
+            }
+            if (S.macros_cap < macros) {
+                if (S.macro_bundles) (void)hipFree(S.macro_bundles);
+                S.macro_bundles = nullptr;
+                S.macros_cap = 0;
+                ++ctx->render_allocs; HIP_TRY(hipMalloc(&S.macro_bundles, sizeof(DevTileBundle) * macros_alloc));
+                S.macros_cap = macros_alloc;
+            }
         }
-        if (B.tiles_cap < tiles) { // (hipFree waits for the device: nothing reads the old buffers any more)
-            if (B.tile_bundles) (void)hipFree(B.tile_bundles);
-            if (B.tile_cnt) (void)hipFree(B.tile_cnt);
-            if (B.tile_list) (void)hipFree(B.tile_list);
-            B.tile_bundles = nullptr; B.tile_cnt = nullptr; B.tile_list = nullptr;
-            B.tiles_cap = 0;
-            HIP_TRY(hipMalloc(&B.tile_bundles, sizeof(DevTileBundle) * tiles));
-            HIP_TRY(hipMalloc(&B.tile_cnt, sizeof(uint32_t) * tiles));
-            HIP_TRY(hipMalloc(&B.tile_list, sizeof(uint32_t) * tiles * RTC_TILE_LIST_CAP));
-            B.tiles_cap = tiles;
-        }
-        if (B.macros_cap < macros) {
-            if (B.macro_bundles) (void)hipFree(B.macro_bundles);
-            B.macro_bundles = nullptr;
-            B.macros_cap = 0;
-            HIP_TRY(hipMalloc(&B.macro_bundles, sizeof(DevTileBundle) * macros));
-            B.macros_cap = macros;
-        }
+        rtc_world::BinSet &B = w->bin[w->bin_next++ & 1u];
         // The binning depends on the World (resident since rtc_world_create) and on this launch's cameras only, so it goes
         // to the side stream: it runs beside the PREVIOUS launch's render kernel, which still reads the other set. It must
         // wait for the render kernel that last read THIS set (two launches ago); the render stream waits for the binning.
@@ -698,6 +707,15 @@ extern "C" rtc_status rtc_debug_counters(rtc_context *ctx, unsigned long long *o
     return RTC_OK;
 }
 
+// Diagnostic (not part of include/rtc.h): device allocations made by the render entry points of this context so far — the
+// binning sets and rtc_render's scratch canvas. A frame sequence must stop allocating after its first launch
+// (tests/test_gpu_group.py::test_render_paths_stop_allocating_after_the_first_launch).
+extern "C" rtc_status rtc_debug_render_allocs(rtc_context *ctx, unsigned long long *out) {
+    if (!ctx || !out) return RTC_ERR_ARG;
+    *out = ctx->render_allocs;
+    return RTC_OK;
+}
+
 rtc_status rtc_stats_reset(rtc_context *ctx) {
     if (!ctx) return RTC_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -782,7 +800,7 @@ rtc_status rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *ca
         if (ctx->d_canvas) (void)hipFree(ctx->d_canvas);
         ctx->d_canvas = nullptr;
         ctx->canvas_bytes = 0;
-        HIP_TRY(hipMalloc(&ctx->d_canvas, bytes));
+        ++ctx->render_allocs; HIP_TRY(hipMalloc(&ctx->d_canvas, bytes));
         ctx->canvas_bytes = bytes;
     }
     double *d = ctx->d_canvas;

@@ -14,6 +14,7 @@ enum { SRC_SMEM = 0, SRC_LDS1 = 1, SRC_LDSN = 2, SRC_CULL = 3, SRC_CULL2 = 4 };
 
 struct rtc_context {
     int device = -1;
+    unsigned long long render_allocs = 0; // hipMalloc calls made by render entry points (rtc_debug_render_allocs)
     unsigned long long pixels = 0; // rtc_stats::pixels of the launches since the last reset (counted by render_launch)
     hipStream_t stream = nullptr;
     unsigned long long *d_counters = nullptr;

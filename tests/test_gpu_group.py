@@ -316,3 +316,40 @@ def test_tile_lists_of_worlds_beyond_65536_objects(rtc):
     assert sa["rays_shadow"] > 100_000
     ctx_bin.close()
     ctx_walk.close()
+
+
+def test_render_paths_stop_allocating_after_the_first_launch(rtc, scenes):
+    """A frame sequence must not call hipMalloc / hipFree after its first launch (they wait for the device: 0.2-3 ms in the
+    middle of a sequence). The case that did: a launch of FEWER views (a 5-frame warm-up) between launches of 8 left one of
+    the two binning sets too small, and the next 8-view launch re-allocated it inside the timed region of
+    `bench.py --steps 20 --warmup 5` (0.09-0.22 ms per frame instead of 0.07). Both sets are now made ready by the first
+    binned launch, for RTC_MAX_VIEWS views. rtc_render's scratch canvas: allocated once."""
+    import ctypes as C
+    import torch
+    lib = rtc.lib()
+    lib.rtc_debug_render_allocs.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong)]
+
+    def allocs(ctx):
+        out = C.c_ulonglong(0)
+        assert lib.rtc_debug_render_allocs(ctx._h, C.byref(out)) == 0
+        return out.value
+
+    for n in (100, 2000):                 # one-level world (binned from 4 views per launch), two-level world (always binned)
+        w, cam = scenes.synthetic(n, 320, 184)
+        ctx = rtc.Context(0)
+        dw = ctx.upload(w)
+        buf = torch.zeros((8 * 184, 320, 3), dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        dw.render_views([cam] * 4, 0, 1, buf.data_ptr(), 184)
+        ctx.synchronize()
+        first = allocs(ctx)
+        assert first > 0
+        for views in (8, 5, 8, 8, 1, 8, 4, 8):
+            dw.render_views([cam] * views, 0, 1, buf.data_ptr(), 184)
+        ctx.synchronize()
+        assert allocs(ctx) == first, (n, first, allocs(ctx))
+        a = dw.render(cam)
+        mid = allocs(ctx)
+        b = dw.render(cam)
+        assert allocs(ctx) == mid and np.array_equal(a, b)
+        ctx.close()
