@@ -80,6 +80,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (bounded sample)")
     ap.add_argument("--no-dropin", action="store_true", help="skip the host-canvas (PCIe-inclusive) drop-in measurements")
+    ap.add_argument("--dropin-multi", action="store_true",
+                    help="N > 1: also measure the shared host canvas that every rank fills over its own PCIe link (off by default: "
+                         "it has only been rehearsed with one rank, and nothing may endanger the headline line of a multi-GPU run)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the single-view / other-exchange secondary runs")
     ap.add_argument("--lean", action="store_true", help="= --no-cpu-baseline --no-dropin --no-secondary (profiling runs)")
     a = ap.parse_args()
@@ -315,7 +318,7 @@ def main():
 
     # ---- host-canvas drop-in (PCIe-inclusive), all ranks fill ONE shared host canvas side by side
     dropin = None
-    if not args.no_dropin:
+    if not args.no_dropin and (not grouped or N == 1 or args.dropin_multi):
         dropin = measure_dropin(rtc, np, torch, dev_index, world, cam, grouped, group if grouped else None,
                                 gworld if grouped else None, rank, N, barrier)
 
