@@ -248,7 +248,7 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
     }
     if (const char *e = std::getenv("RTC_BINNING")) ctx->binning = std::atoi(e) != 0;
     if (const char *e = std::getenv("RTC_LIGHT_LISTS")) ctx->light_lists = std::atoi(e) != 0;
-    if (const char *e = std::getenv("RTC_BIN_SMALL_VIEWS")) ctx->bin_small_views = (uint32_t)std::atoi(e);
+    if (const char *e = std::getenv("RTC_BIN_SMALL_PIXELS")) ctx->bin_small_pixels = std::strtoull(e, nullptr, 10);
     if (const char *e = std::getenv("RTC_TILE_CAP")) {
         const int v = std::atoi(e);
         if (v >= 16 && v <= 1024) ctx->tile_cap = (uint32_t)v;
@@ -502,11 +502,8 @@ void rtc_world_destroy(rtc_world *w) {
     if (w->d_gbound) (void)hipFree(w->d_gbound);
     if (w->d_idtab) (void)hipFree(w->d_idtab);
     for (rtc_world::BinSet &b : w->bin) {
-        if (b.tile_bundles) (void)hipFree(b.tile_bundles);
-        if (b.macro_bundles) (void)hipFree(b.macro_bundles);
         if (b.tile_cnt) (void)hipFree(b.tile_cnt);
         if (b.tile_list) (void)hipFree(b.tile_list);
-        if (b.wide) (void)hipFree(b.wide);
         if (b.binned) (void)hipEventDestroy(b.binned);
         if (b.traced) (void)hipEventDestroy(b.traced);
     }
@@ -554,48 +551,37 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     }
     // binned primary pass (two-level worlds, tile rows aligned with the image's): three small kernels put
     // every object on the list of each 8x8 tile its bounding sphere can touch (same conservative predicate as the wave-level
-    // cull), so the render kernel's primary pass runs exact tests on a short list instead of walking the groups
-    // (small worlds, one-level cull: only in launches of several views, where the binning hides behind the previous launch)
-    // (and only for whole frames: one rank's share of a 100-object frame renders faster than the frame's binning)
-    const bool bin_this = (src == SRC_CULL2) || (src == SRC_CULL && nviews >= ctx->bin_small_views && band_stride == 1u && y0 == 0u && y1 == cam->vsize);
+    // cull), so the render kernel's primary pass runs exact tests on a short list instead of walking the groups. Two-level
+    // worlds always; one-level worlds when the launch is long enough (bin_small_pixels) and covers whole frames (one rank's
+    // share of a 100-object frame renders faster than the frame's binning).
+    const bool bin_this = (src == SRC_CULL2) ||
+                          (src == SRC_CULL && (unsigned long long)nviews * cam->hsize * cam->vsize >= ctx->bin_small_pixels &&
+                           band_stride == 1u && y0 == 0u && y1 == cam->vsize);
     rtc_world::BinSet *binset = nullptr;
     if (bin_this && ctx->binning && (y0 % 8u) == 0u && w->n != 0u) {
         const uint32_t tiles_x = (cam->hsize + 7u) / 8u, tiles_y = (cam->vsize + 7u) / 8u;
-        const uint32_t macros_x = (tiles_x + 7u) / 8u, macros_y = (tiles_y + 7u) / 8u;
-        // macro tiles and super tiles (8x8 macro tiles) share one buffer
-        const size_t tiles = (size_t)tiles_x * tiles_y * nviews,
-                     macros = ((size_t)macros_x * macros_y + (size_t)((macros_x + 7u) / 8u) * ((macros_y + 7u) / 8u)) * nviews;
+        const size_t tiles = (size_t)tiles_x * tiles_y * nviews;
         if (!ctx->side_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
         // Capacity. Both sets are made ready by the FIRST binned launch, and for RTC_MAX_VIEWS views whenever that stays small
-        // (1080p: 69 MB per set; exactly the launch's views otherwise): a launch sequence must not allocate after its first
+        // (1080p: 67 MB per set; exactly the launch's views otherwise): a launch sequence must not allocate after its first
         // launch — hipMalloc / hipFree wait for the device, 0.2-3 ms in the middle of a frame sequence (a 5-frame warm-up
         // launch followed by 8-frame launches did exactly that: 0.09-0.22 ms per frame instead of 0.07).
-        const size_t per_view_bytes = (size_t)tiles_x * tiles_y * (sizeof(DevTileBundle) + sizeof(uint32_t) * (1u + RTC_TILE_LIST_CAP));
+        const size_t per_view_bytes = (size_t)tiles_x * tiles_y * sizeof(uint32_t) * (1u + RTC_TILE_LIST_CAP);
         const uint32_t alloc_views = per_view_bytes <= ((size_t)128 << 20) ? (uint32_t)RTC_MAX_VIEWS : nviews;
-        const size_t tiles_alloc = (size_t)tiles_x * tiles_y * alloc_views, macros_alloc = macros / nviews * alloc_views;
+        const size_t tiles_alloc = (size_t)tiles_x * tiles_y * alloc_views;
         for (rtc_world::BinSet &S : w->bin) {
             if (!S.binned) {
                 HIP_TRY(hipEventCreateWithFlags(&S.binned, hipEventDisableTiming));
                 HIP_TRY(hipEventCreateWithFlags(&S.traced, hipEventDisableTiming));
-                ++ctx->render_allocs; HIP_TRY(hipMalloc(&S.wide, sizeof(uint32_t) * RTC_MAX_VIEWS * (RTC_BIN_WIDE_CAP + 1u)));
             }
             if (S.tiles_cap < tiles) { // (hipFree waits for the device: nothing reads the old buffers any more)
-                if (S.tile_bundles) (void)hipFree(S.tile_bundles);
                 if (S.tile_cnt) (void)hipFree(S.tile_cnt);
                 if (S.tile_list) (void)hipFree(S.tile_list);
-                S.tile_bundles = nullptr; S.tile_cnt = nullptr; S.tile_list = nullptr;
+                S.tile_cnt = nullptr; S.tile_list = nullptr;
                 S.tiles_cap = 0;
-                ++ctx->render_allocs; HIP_TRY(hipMalloc(&S.tile_bundles, sizeof(DevTileBundle) * tiles_alloc));
                 ++ctx->render_allocs; HIP_TRY(hipMalloc(&S.tile_cnt, sizeof(uint32_t) * tiles_alloc));
                 ++ctx->render_allocs; HIP_TRY(hipMalloc(&S.tile_list, sizeof(uint32_t) * tiles_alloc * RTC_TILE_LIST_CAP));
                 S.tiles_cap = tiles_alloc;
-            }
-            if (S.macros_cap < macros) {
-                if (S.macro_bundles) (void)hipFree(S.macro_bundles);
-                S.macro_bundles = nullptr;
-                S.macros_cap = 0;
-                ++ctx->render_allocs; HIP_TRY(hipMalloc(&S.macro_bundles, sizeof(DevTileBundle) * macros_alloc));
-                S.macros_cap = macros_alloc;
             }
         }
         rtc_world::BinSet &B = w->bin[w->bin_next++ & 1u];
@@ -603,15 +589,14 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
         // to the side stream: it runs beside the PREVIOUS launch's render kernel, which still reads the other set. It must
         // wait for the render kernel that last read THIS set (two launches ago); the render stream waits for the binning.
         HIP_TRY(hipStreamWaitEvent(ctx->side_stream, B.traced, 0)); // never recorded: no wait
-        HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound, B.tile_bundles, B.macro_bundles, B.tile_cnt,
-                                   B.tile_list, B.wide, y0 / 8u, band_stride, ctx->side_stream));
+        HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound_s, w->d_gbound, w->d_orig_s, w->ngroups, B.tile_cnt,
+                                   B.tile_list, y0 / 8u, band_stride, ctx->side_stream));
         HIP_TRY(hipEventRecord(B.binned, ctx->side_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, B.binned, 0));
         P.tile_cnt = B.tile_cnt;
         P.tile_list = B.tile_list;
         P.tiles_x = tiles_x;
         P.tiles_y = tiles_y;
-        P.bin_wide = B.wide;
         P.bin_packed = RTC_BIN_PACKED(w->n) ? 1u : 0u;
         P.n_unb = w->n_unb;
         binset = &B;

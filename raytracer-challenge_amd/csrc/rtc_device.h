@@ -52,23 +52,17 @@ struct DevBound {
     double k;             // 0.75e-14 * ||A||_F^2 (A = 3x3 of the stored inverse): rounding inflation
     double cn;            // |centre|: see the note on rounding below
 };
-// Binned primary pass (two-level worlds, one ray per pixel). Per render and view three small kernels put every object on
-// the list of each 8x8-pixel tile whose primary-ray bundle its bounding sphere can touch — the SAME conservative predicate
-// the wave-level cull applies (bundle_touches), evaluated from the object's side against the tile's own bundle
-// (k_tile_bundles builds it from the tile's 64 rays exactly as the render kernel would). The render kernel's primary pass
-// then runs the exact test on its tile's list (1.8 objects on average at 10 000 spheres) instead of walking 157 group
-// spheres and expanding 17 groups. A tile whose list overflows RTC_TILE_LIST_CAP falls back to the walk.
+// Binned primary pass. Per render and view one kernel (k_bin_tiles) puts every object on the list of each 8x8-pixel tile
+// whose primary-ray cone its bounding sphere can touch — the SAME conservative predicate the wave-level cull applies
+// (bundle_touches), against a cone built from the tile's corner rays (cell_cone). The render kernel's primary pass then runs
+// the exact test on its tile's list (1.8 objects on average at 10 000 spheres) instead of walking 157 group spheres and
+// expanding 17 groups. A tile whose list overflows RTC_TILE_LIST_CAP falls back to the walk. Unbounded objects (planes) are
+// never listed: they are the first `n_unb` entries of the Morton-sorted tables and every tile tests them.
 struct DevTileBundle {
     float ax, ay, az, cosT, sinT; // cone around the tile's (or macro tile's) rays; apex = the view's camera origin
     uint32_t off;                 // 1: could not be bounded — every object is a candidate
 };
 #define RTC_TILE_LIST_CAP 64u // one lane per entry in the render kernel's nearest-first walk
-// An object that touches more than RTC_BIN_WIDE macro tiles (64x64 pixels each) is deferred to a second kernel that gives
-// it one wave per super tile (a single wave appending to thousands of tiles would run for milliseconds); the per-view list
-// of deferred objects holds RTC_BIN_WIDE_CAP entries — if it overflows, that view's tiles fall back to the walk. Unbounded
-// objects (planes) are never binned: they are the first `n_unb` entries of the Morton-sorted tables and every tile tests them.
-#define RTC_BIN_WIDE 16u
-#define RTC_BIN_WIDE_CAP 1024u
 
 // Light-space shadow lists (two-level worlds). Every shadow segment ends at the light (is_shadowed_by_light shape.rs:716-720),
 // so seen from the light it is a ray in some direction: a cube map of RTC_LIGHT_R x RTC_LIGHT_R direction cells per face
@@ -163,7 +157,6 @@ struct RenderParams {
     uint32_t light_cap;          // entries per cell of THIS World's lists
     double light_reach;
     uint32_t bin_packed;        // tile-list entries carry the upper half of the object's key above its index (RTC_BIN_PACKED)
-    const uint32_t *bin_wide;   // per view: [0] number of deferred wide objects (> RTC_BIN_WIDE_CAP: the lists are incomplete)
     uint32_t n_unb;             // unbounded objects = the first n_unb entries of isect_s / kind_s / orig_s
     uint32_t ngroups;
     uint32_t n;

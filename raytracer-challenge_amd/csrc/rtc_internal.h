@@ -40,7 +40,9 @@ struct rtc_context {
     // other (north star, 8 views per launch: 0.0745 -> 0.0685 ms per frame; 4 views: 0.0732 -> 0.0704; C4 1.48 -> 1.42;
     // C2 unchanged) but not in front of a lone one-view launch (0.0824 -> 0.0895). Before the side stream the same binning
     // gave the render kernel its 12 % and took it all back in launch latency (profiles/r02_exp_binned_small_worlds.log).
-    uint32_t bin_small_views = 4;
+    // one-level worlds (n <= 256) are binned when the launch is long enough for the extra kernel and its two cross-stream
+    // events to pay: views x pixels >= this (RTC_BIN_SMALL_PIXELS; 1080p: from 3 views per launch, 4096^2: always)
+    unsigned long long bin_small_pixels = 6000000ull;
 };
 
 struct rtc_world {
@@ -61,11 +63,9 @@ struct rtc_world {
     // binned primary pass: per-render scratch, grow-only, TWO sets — the binning of launch k+1 runs on the context's side
     // stream while launch k's render kernel still reads set k (rtc_render_* take the World as const: mutable)
     struct BinSet {
-        DevTileBundle *tile_bundles = nullptr, *macro_bundles = nullptr;
-        uint32_t *tile_cnt = nullptr, *tile_list = nullptr;
-        uint32_t *wide = nullptr;        // [RTC_MAX_VIEWS][1 + RTC_BIN_WIDE_CAP]: deferred wide objects per view
-        size_t tiles_cap = 0, macros_cap = 0; // capacity in (view, tile) / (view, macro tile) entries
-        hipEvent_t binned = nullptr;     // recorded on the side stream after the set's binning kernels
+        uint32_t *tile_cnt = nullptr, *tile_list = nullptr; // per (view, tile): entries used, RTC_TILE_LIST_CAP entry slots
+        size_t tiles_cap = 0;            // capacity in (view, tile) entries
+        hipEvent_t binned = nullptr;     // recorded on the side stream after the set's binning kernel
         hipEvent_t traced = nullptr;     // recorded on the render stream after the render kernel that read the set
     };
     mutable BinSet bin[2];
@@ -82,9 +82,9 @@ struct rtc_world {
 };
 
 
-extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound,
-                                         DevTileBundle *tile_bundles, DevTileBundle *macro_bundles, uint32_t *cnt, uint32_t *list,
-                                         uint32_t *wide, uint32_t row0, uint32_t row_stride, hipStream_t stream);
+extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound_s,
+                                         const DevBound *gbound, const uint32_t *orig_s, uint32_t ngroups, uint32_t *cnt, uint32_t *list,
+                                         uint32_t row0, uint32_t row_stride, hipStream_t stream);
 extern "C" hipError_t rtc_launch_light_lists(uint32_t n, uint32_t cap, const DevBound *bound, const double light[3], double reach, DevTileBundle *cells,
                                              DevTileBundle *macros, uint32_t *cnt, uint32_t *list, hipStream_t stream);
 extern "C" hipError_t rtc_launch_undeal(const void *staging, void *canvas, uint32_t nranks, uint32_t nframes, uint32_t H,

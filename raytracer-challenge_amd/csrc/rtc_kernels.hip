@@ -1049,8 +1049,8 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
 #endif
     STAMP(0);
 
-    // Binned primary pass: this wave's 8x8 tile has a list of the objects its primary rays can touch (k_bin_objects /
-    // k_bin_wide): lane e holds entry e. (RTC_BIN_HOIST: the 64 entry slots of a tile always exist, the ones past the
+    // Binned primary pass: this wave's 8x8 tile has a list of the objects its primary rays can touch (k_bin_tiles): lane e
+    // holds entry e. (RTC_BIN_HOIST: the 64 entry slots of a tile always exist, the ones past the
     // count hold garbage and are masked in the walk.)
     bool binned = false;
     uint32_t bin_cnt = 0, bin_ent = 0xffffffffu;
@@ -1068,8 +1068,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 bin_cnt = (uint32_t)__builtin_amdgcn_readfirstlane((int)Pt.tile_cnt[tile]);
                 if (lane < bin_cnt) bin_ent = Pt.tile_list[tile * RTC_TILE_LIST_CAP + lane];
 #endif
-                // an overflowing list (the tile's, or the view's list of deferred wide objects) is incomplete: walk instead
-                binned = bin_cnt <= RTC_TILE_LIST_CAP && Pt.bin_wide[(size_t)view * (RTC_BIN_WIDE_CAP + 1u)] <= RTC_BIN_WIDE_CAP;
+                binned = bin_cnt <= RTC_TILE_LIST_CAP; // an overflowing list is incomplete: walk instead
             }
         }
     };
@@ -1234,7 +1233,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 }, ro, rd, NoSkip{}, DIAG_PTR(6), DIAG_PTR(8), DIAG_PTR(10));
 #endif
             } else if (IS_CULL(SRC) && !PROBE && use_bins) {
-                // binned primary pass: the unbounded objects, then the tile's own list (k_bin_objects / k_bin_wide) — together
+                // binned primary pass: the unbounded objects, then the tile's own list (k_bin_tiles) — together
                 // every object this tile's rays can touch
                 const auto &Pb = KP(P_arg);
                 for (uint32_t k = 0; k < Pb.n_unb; ++k) {
@@ -1898,7 +1897,7 @@ DEVI V3 primary_dir(const DevCamera &C, V3 cam_origin, uint32_t px, uint32_t py,
 struct BinParams {
     DevCamera views[RTC_MAX_VIEWS];
     uint32_t nviews, W, H, n;
-    uint32_t tiles_x, tiles_y, macros_x, macros_y, supers_x, supers_y; // 8x8 pixels, 8x8 tiles, 8x8 macro tiles
+    uint32_t tiles_x, tiles_y, macros_x, macros_y; // tiles of 8x8 pixels, macro tiles of 8x8 tiles
     uint32_t packed;           // n <= 65 536: list entries carry the key (bin_entry)
     uint32_t row0, row_stride; // the launch renders tile rows row0, row0 + row_stride, ... only (one rank's bands): the others get no lists
 };
@@ -1922,7 +1921,12 @@ DEVI bool dir_f32(V3 d, float &fx, float &fy, float &fz) {
     return finite3(d) && l2 > 1e-30f && l2 < 1e30f;
 }
 
-// The cone of the primary rays of the `cell` x `cell` pixel block at (x0, y0), clipped to the image (see k_cell_bundles).
+// The cone of the primary rays of the `cell` x `cell` pixel block at (x0, y0), clipped to the image, with make_bundle's
+// arithmetic and margins but from five rays instead of all: the axis ray (a pixel near the block's centre) and the four
+// corners. The angle between a ray through the image plane and a fixed axis is a quasi-convex function of the pixel
+// position (its sub-level sets are the interiors of conic sections), so over the block's rectangle it peaks at a corner;
+// the reference arithmetic's rounding (1e-16) and the f32 conversion (6e-8) sit far inside make_bundle's margins
+// (sinT * 1.001 + 4e-6). All pixels inside the image count: a superset of the lanes Camera::render traces.
 DEVI DevTileBundle cell_cone(const BinParams &Q, uint32_t view, uint32_t x0, uint32_t y0, uint32_t cell) {
 #pragma clang fp contract(fast)
     const uint32_t x1 = min(x0 + cell - 1u, Q.W - 1u), y1 = min(y0 + cell - 1u, Q.H - 1u);
@@ -1951,31 +1955,6 @@ DEVI DevTileBundle cell_cone(const BinParams &Q, uint32_t view, uint32_t x0, uin
     return r;
 }
 
-// One THREAD per (view, cell) for all three levels at once — tiles of 8x8 pixels, macro tiles of 64x64, super tiles of
-// 512x512: the cone of the cell's primary rays with make_bundle's arithmetic and margins, from five rays instead of all:
-// the axis ray (a pixel near the cell's centre) and the four corner pixels. The angle between a ray through the image
-// plane and a fixed axis is a quasi-convex function of the pixel position (its sub-level sets are the interiors of conic
-// sections), so over the cell's rectangle of pixel centres it peaks at a corner; the reference arithmetic's rounding
-// (1e-16) and the f32 conversion (6e-8) sit far inside make_bundle's margins (sinT * 1.001 + 4e-6). All pixels inside the
-// image count: a superset of the lanes Camera::render traces; the corners are those of the pixel AREAS, so every
-// sub-pixel offset is inside too. Tile threads also clear their tile's list counter.
-__global__ void __launch_bounds__(256) k_cell_bundles(const BinParams Q, DevTileBundle *__restrict__ tiles_out,
-                                                      DevTileBundle *__restrict__ macros_out, DevTileBundle *__restrict__ supers_out,
-                                                      uint32_t *__restrict__ cnt, uint32_t *__restrict__ wide) {
-#pragma clang fp contract(fast)
-    const uint32_t nt = Q.nviews * Q.tiles_x * Q.tiles_y, nm = Q.nviews * Q.macros_x * Q.macros_y, ns = Q.nviews * Q.supers_x * Q.supers_y;
-    uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < Q.nviews * (RTC_BIN_WIDE_CAP + 1u)) wide[i] = 0u; // the views' lists of deferred (wide) objects: count + entries
-    uint32_t gx, gy, cell;
-    DevTileBundle *out;
-    if (i < nt) { gx = Q.tiles_x; gy = Q.tiles_y; cell = 8u; out = tiles_out; cnt[i] = 0u; }
-    else if ((i -= nt) < nm) { gx = Q.macros_x; gy = Q.macros_y; cell = 64u; out = macros_out; }
-    else if ((i -= nm) < ns) { gx = Q.supers_x; gy = Q.supers_y; cell = 512u; out = supers_out; }
-    else return;
-    const uint32_t view = i / (gx * gy), t = i % (gx * gy);
-    out[i] = cell_cone(Q, view, (t % gx) * cell, (t / gx) * cell, cell);
-}
-
 // A tile-list entry: the object's index and, while the indices fit 16 bits (BinParams::packed), the upper half of its
 // key above it — bound_key from the view's camera, truncated towards zero (keys are >= 0), so still a lower bound.
 DEVI uint32_t bin_entry(const BinParams &Q, V3 o, const DevBound &b, uint32_t j) {
@@ -1983,108 +1962,63 @@ DEVI uint32_t bin_entry(const BinParams &Q, V3 o, const DevBound &b, uint32_t j)
     return (__builtin_bit_cast(uint32_t, bound_key(o, b)) & 0xffff0000u) | j;
 }
 
-// Level 3 of the binning: the tiles of macro tile (mxs, mys), one per lane.
-DEVI void bin_tiles_of_macro(const BinParams &Q, uint32_t view, uint32_t mxs, uint32_t mys, uint32_t lane, V3 o, const DevBound &b, uint32_t entry,
-                             const DevTileBundle *__restrict__ tb, uint32_t *__restrict__ cnt, uint32_t *__restrict__ list) {
-    const uint32_t tx = mxs * 8u + (lane & 7u), ty = mys * 8u + (lane >> 3);
-    if (tx < Q.tiles_x && ty < Q.tiles_y && ty >= Q.row0 && (ty - Q.row0) % Q.row_stride == 0u) {
-        const size_t tile = (size_t)(view * Q.tiles_y + ty) * Q.tiles_x + tx;
-        if (bundle_touches(bundle_of(tb[tile], o), b)) {
-            const uint32_t slot = atomicAdd(cnt + tile, 1u);
-            if (slot < RTC_TILE_LIST_CAP) list[tile * RTC_TILE_LIST_CAP + slot] = entry;
-        }
-    }
-}
-
-// One wave per (view, object): the object goes on the list of every tile whose cone its bounding sphere can touch
-// (bundle_touches, the wave-level cull's predicate). Three levels, 64 cells per step, one per lane: super tiles, the macro
-// tiles of touched super tiles, the tiles of touched macro tiles. Pass 1 counts the macro tiles touched; an object that
-// touches more than RTC_BIN_WIDE of them is DEFERRED to k_bin_wide, which spreads it over one wave per super tile (one
-// wave appending to thousands of tiles would run for milliseconds).
-__global__ void __launch_bounds__(64) k_bin_objects(const BinParams Q, const DevBound *__restrict__ bound, const DevTileBundle *__restrict__ tb,
-                                                     const DevTileBundle *__restrict__ mb, const DevTileBundle *__restrict__ sb,
-                                                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ list, uint32_t *__restrict__ wide) {
-    const uint32_t view = blockIdx.x / Q.n, j = blockIdx.x % Q.n, lane = threadIdx.x;
-    const DevBound b = bound[j];
-    if (!(b.r < __builtin_inf())) return; // unbounded: every tile tests it anyway (the sorted tables' first n_unb entries)
+// The binning kernel: one wave per (view, macro tile of 64x64 pixels), lane = one of its 8x8 tiles of 8x8 pixels. Every
+// object goes on the list of each tile whose cone (cell_cone) its bounding sphere can touch — bundle_touches, the wave-level
+// cull's own conservative predicate. The wave first finds the objects its MACRO tile's cone can touch through the World's
+// two-level tables (groups of 64 Morton-ordered objects, a sphere around each group: lane = group, then lane = member);
+// every lane then tests those survivors — fetched by uniform index — against its own tile's cone and appends to its own
+// list: no atomics, entries in table order, one launch per render. (Round 2 first PUSHED the objects into the tiles — one
+// wave per (view, object), atomic appends, a second kernel for objects that cover many tiles, a third for the cones: the
+// same lists at 3x the launches; C3 -2 %, C5 -3 %, one camera per launch C3 -11 % for this form,
+// profiles/r02_exp_pull_binning.log.)
+__global__ void __launch_bounds__(64) k_bin_tiles(const BinParams Q, const DevBound *__restrict__ bound_s, const DevBound *__restrict__ gbound,
+                                                   const uint32_t *__restrict__ orig_s, uint32_t ngroups, uint32_t *__restrict__ cnt,
+                                                   uint32_t *__restrict__ list) {
+    const uint32_t macros = Q.macros_x * Q.macros_y;
+    const uint32_t view = blockIdx.x / macros, m = blockIdx.x % macros, lane = threadIdx.x;
+    const uint32_t mx = m % Q.macros_x, my = m / Q.macros_x;
+    const uint32_t tx = mx * 8u + (lane & 7u), ty = my * 8u + (lane >> 3);
+    const bool mine = tx < Q.tiles_x && ty < Q.tiles_y && ty >= Q.row0 && (ty - Q.row0) % Q.row_stride == 0u;
+    if (ballot(mine) == 0ull) return; // the launch renders none of this macro tile's rows
     const DevCamera &C = Q.views[view];
     V3 o = xpoint(C.vinv, mk(0., 0., 0.));
     o = mk(uniform_f64(o.x), uniform_f64(o.y), uniform_f64(o.z));
-    const uint32_t supers = Q.supers_x * Q.supers_y, macros = Q.macros_x * Q.macros_y;
-    const uint32_t entry = bin_entry(Q, o, b, j);
-    for (int pass = 0; pass < 2; ++pass) {
-        uint32_t touched = 0;
-        for (uint32_t sbase = 0; sbase < supers; sbase += 64u) {
-            const uint32_t sidx = sbase + lane;
-            bool ts = false;
-            if (sidx < supers) ts = bundle_touches(bundle_of(sb[(size_t)view * supers + sidx], o), b);
-            unsigned long long smask = ballot(ts);
-            while (smask) {
-                const uint32_t ssel = sbase + (uint32_t)__builtin_ctzll(smask);
-                smask &= smask - 1ull;
-                const uint32_t mx = (ssel % Q.supers_x) * 8u + (lane & 7u), my = (ssel / Q.supers_x) * 8u + (lane >> 3);
-                bool tm = false;
-                if (mx < Q.macros_x && my < Q.macros_y) tm = bundle_touches(bundle_of(mb[(size_t)view * macros + my * Q.macros_x + mx], o), b);
-                unsigned long long mmask = ballot(tm);
-                touched += popc64(mmask);
-                if (pass == 0) {
-                    if (touched > RTC_BIN_WIDE) {
-                        if (lane == 0) {
-                            uint32_t *wl = wide + (size_t)view * (RTC_BIN_WIDE_CAP + 1u);
-                            const uint32_t slot = atomicAdd(wl, 1u);
-                            if (slot < RTC_BIN_WIDE_CAP) wl[1u + slot] = j;
-                        }
-                        return;
-                    }
-                    continue;
-                }
-                while (mmask) {
-                    const uint32_t l = (uint32_t)__builtin_ctzll(mmask);
-                    mmask &= mmask - 1ull;
-                    bin_tiles_of_macro(Q, view, (ssel % Q.supers_x) * 8u + (l & 7u), (ssel / Q.supers_x) * 8u + (l >> 3), lane, o, b, entry, tb, cnt, list);
+    const Bundle MB = bundle_of(cell_cone(Q, view, mx * 64u, my * 64u, 64u), o);
+    const Bundle TB = bundle_of(cell_cone(Q, view, min(tx, Q.tiles_x - 1u) * 8u, min(ty, Q.tiles_y - 1u) * 8u, 8u), o);
+    const size_t tile = (size_t)(view * Q.tiles_y + min(ty, Q.tiles_y - 1u)) * Q.tiles_x + min(tx, Q.tiles_x - 1u);
+    uint32_t *my_list = list + tile * RTC_TILE_LIST_CAP;
+    uint32_t my_cnt = 0;
+    for (uint32_t gbase = 0; gbase < ngroups; gbase += 64u) {
+        const uint32_t g = gbase + lane;
+        unsigned long long gmask = ballot(g < ngroups && bundle_touches(MB, gbound[g])); // (a group with an unbounded member: r = inf, kept)
+        while (gmask) {
+            const uint32_t gsel = gbase + (uint32_t)__builtin_ctzll(gmask);
+            gmask &= gmask - 1ull;
+            const uint32_t k = gsel * 64u + lane;
+            bool to = false;
+            if (k < Q.n) {
+                const DevBound b = bound_s[k];
+                to = b.r < __builtin_inf() && bundle_touches(MB, b); // unbounded objects are never listed: every tile tests them anyway
+            }
+            unsigned long long omask = ballot(to);
+            while (omask) {
+                const uint32_t ks = gsel * 64u + (uint32_t)__builtin_ctzll(omask);
+                omask &= omask - 1ull;
+                const DevBound bj = bound_s[ks];
+                if (mine && bundle_touches(TB, bj)) {
+                    if (my_cnt < RTC_TILE_LIST_CAP) my_list[my_cnt] = bin_entry(Q, o, bj, orig_s[ks]);
+                    ++my_cnt;
                 }
             }
         }
     }
+    if (mine) cnt[tile] = my_cnt; // > RTC_TILE_LIST_CAP: the list is incomplete and the render wave walks instead
 }
 
-// Deferred (wide) objects: RTC_BIN_WIDE_WORKERS waves per (view, super tile); worker k takes the view's deferred objects
-// k, k + WORKERS, ... and bins each one's tiles inside that super tile.
-#define RTC_BIN_WIDE_WORKERS 32u
-__global__ void __launch_bounds__(64) k_bin_wide(const BinParams Q, const DevBound *__restrict__ bound, const DevTileBundle *__restrict__ tb,
-                                                  const DevTileBundle *__restrict__ mb, const DevTileBundle *__restrict__ sb,
-                                                  uint32_t *__restrict__ cnt, uint32_t *__restrict__ list, const uint32_t *__restrict__ wide) {
-    const uint32_t supers = Q.supers_x * Q.supers_y, macros = Q.macros_x * Q.macros_y;
-    const uint32_t ssel = blockIdx.x % supers, worker = (blockIdx.x / supers) % RTC_BIN_WIDE_WORKERS, view = blockIdx.x / (supers * RTC_BIN_WIDE_WORKERS);
-    const uint32_t lane = threadIdx.x;
-    const uint32_t *wl = wide + (size_t)view * (RTC_BIN_WIDE_CAP + 1u);
-    const uint32_t ndef = min(wl[0], RTC_BIN_WIDE_CAP); // wl[0] > RTC_BIN_WIDE_CAP: the list overflowed, this view's tiles walk (k_trace checks)
-    if (worker >= ndef) return;
-    const DevCamera &C = Q.views[view];
-    V3 o = xpoint(C.vinv, mk(0., 0., 0.));
-    o = mk(uniform_f64(o.x), uniform_f64(o.y), uniform_f64(o.z));
-    const DevTileBundle sbun = sb[(size_t)view * supers + ssel];
-    const uint32_t mx = (ssel % Q.supers_x) * 8u + (lane & 7u), my = (ssel / Q.supers_x) * 8u + (lane >> 3);
-    const bool mvalid = mx < Q.macros_x && my < Q.macros_y;
-    DevTileBundle mbun{0.f, 0.f, 1.f, 1.f, 0.f, 0u};
-    if (mvalid) mbun = mb[(size_t)view * macros + my * Q.macros_x + mx];
-    for (uint32_t d = worker; d < ndef; d += RTC_BIN_WIDE_WORKERS) {
-        const uint32_t j = wl[1u + d];
-        const DevBound b = bound[j];
-        if (!bundle_touches(bundle_of(sbun, o), b)) continue;
-        unsigned long long mmask = ballot(mvalid && bundle_touches(bundle_of(mbun, o), b));
-        const uint32_t entry = bin_entry(Q, o, b, j);
-        while (mmask) {
-            const uint32_t l = (uint32_t)__builtin_ctzll(mmask);
-            mmask &= mmask - 1ull;
-            bin_tiles_of_macro(Q, view, (ssel % Q.supers_x) * 8u + (l & 7u), (ssel / Q.supers_x) * 8u + (l >> 3), lane, o, b, entry, tb, cnt, list);
-        }
-    }
-}
-
-extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound,
-                                         DevTileBundle *tile_bundles, DevTileBundle *macro_bundles, uint32_t *cnt, uint32_t *list,
-                                         uint32_t *wide, uint32_t row0, uint32_t row_stride, hipStream_t stream) {
+extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound_s,
+                                         const DevBound *gbound, const uint32_t *orig_s, uint32_t ngroups, uint32_t *cnt, uint32_t *list,
+                                         uint32_t row0, uint32_t row_stride, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
     BinParams Q;
     Q.row0 = row0; Q.row_stride = row_stride ? row_stride : 1u;
     for (uint32_t v = 0; v < nviews; ++v) Q.views[v] = views[v];
@@ -2093,18 +2027,7 @@ extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews
     Q.packed = RTC_BIN_PACKED(n) ? 1u : 0u;
     Q.tiles_x = (W + 7u) / 8u; Q.tiles_y = (H + 7u) / 8u;
     Q.macros_x = (Q.tiles_x + 7u) / 8u; Q.macros_y = (Q.tiles_y + 7u) / 8u;
-    Q.supers_x = (Q.macros_x + 7u) / 8u; Q.supers_y = (Q.macros_y + 7u) / 8u;
-    const uint32_t tiles = Q.tiles_x * Q.tiles_y, macros = Q.macros_x * Q.macros_y, supers = Q.supers_x * Q.supers_y;
-    DevTileBundle *super_bundles = macro_bundles + (size_t)nviews * macros; // the caller sized macro_bundles for both levels
-    const uint32_t cells = nviews * (tiles + macros + supers), need = nviews * (RTC_BIN_WIDE_CAP + 1u);
-    hipLaunchKernelGGL(k_cell_bundles, dim3(((cells > need ? cells : need) + 255u) / 256u), dim3(256), 0, stream, Q, tile_bundles, macro_bundles,
-                       super_bundles, cnt, wide);
-    if (n) {
-        hipLaunchKernelGGL(k_bin_objects, dim3(nviews * n), dim3(64), 0, stream, Q, bound, (const DevTileBundle *)tile_bundles,
-                           (const DevTileBundle *)macro_bundles, (const DevTileBundle *)super_bundles, cnt, list, wide);
-        hipLaunchKernelGGL(k_bin_wide, dim3(nviews * RTC_BIN_WIDE_WORKERS * supers), dim3(64), 0, stream, Q, bound, (const DevTileBundle *)tile_bundles,
-                           (const DevTileBundle *)macro_bundles, (const DevTileBundle *)super_bundles, cnt, list, (const uint32_t *)wide);
-    }
+    hipLaunchKernelGGL(k_bin_tiles, dim3(nviews * Q.macros_x * Q.macros_y), dim3(64), 0, stream, Q, bound_s, gbound, orig_s, ngroups, cnt, list);
     return hipGetLastError();
 }
 

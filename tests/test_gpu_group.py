@@ -220,13 +220,12 @@ def _ctx_env(rtc, **env):
 
 
 def test_binned_primary_pass_and_light_lists_equal_the_group_walk(rtc, O, scenes):
-    """Two-level worlds take their primary rays' candidates from per-view tile lists (k_cell_bundles / k_bin_objects /
-    k_bin_wide) and their shadow rays' candidates from the light-space direction-cell lists built once per World
+    """Two-level worlds take their primary rays' candidates from per-view tile lists (k_bin_tiles) and their shadow rays'
+    candidates from the light-space direction-cell lists built once per World
     (k_light_cells / k_light_bin), instead of walking the groups. Same conservative predicate, so the canvases must equal
     the walk's (RTC_BINNING=0 RTC_LIGHT_LISTS=0) and brute force bit for bit with identical ray counts — including the cases
     the lists cannot serve:
-    tiles whose list overflows (many objects behind few pixels), objects that cover most of the screen (deferred to
-    k_bin_wide), unbounded objects (planes: the sorted tables' prefix), row ranges that do not start on a tile row (no
+    tiles whose list overflows (many objects behind few pixels), objects that cover most of the screen, unbounded objects (planes: the sorted tables' prefix), row ranges that do not start on a tile row (no
     binning), Camera::render's untraced last row/column, interleaved bands, several views per launch, and a reflective
     world (first pass binned, secondary passes not)."""
     import torch
@@ -334,9 +333,9 @@ def test_render_paths_stop_allocating_after_the_first_launch(rtc, scenes):
         assert lib.rtc_debug_render_allocs(ctx._h, C.byref(out)) == 0
         return out.value
 
-    for n in (100, 2000):                 # one-level world (binned from 4 views per launch), two-level world (always binned)
+    for n in (100, 2000):                 # one-level world (binned in long launches: forced here), two-level world (always binned)
         w, cam = scenes.synthetic(n, 320, 184)
-        ctx = rtc.Context(0)
+        ctx = _ctx_env(rtc, RTC_BIN_SMALL_PIXELS=0)
         dw = ctx.upload(w)
         buf = torch.zeros((8 * 184, 320, 3), dtype=torch.float64, device="cuda:0")
         torch.cuda.synchronize()
@@ -353,3 +352,59 @@ def test_render_paths_stop_allocating_after_the_first_launch(rtc, scenes):
         b = dw.render(cam)
         assert allocs(ctx) == mid and np.array_equal(a, b)
         ctx.close()
+
+
+def test_one_level_worlds_binned_equal_the_walk(rtc, O, scenes):
+    """Worlds of up to 256 objects (one-level cull) take the binned primary pass only in long launches (views x pixels >=
+    RTC_BIN_SMALL_PIXELS: the bench's 8-view 1080p launches, 4096^2 frames); forced here on small canvases. Same lists, same
+    consumer as for large worlds, but the other kernel instantiations (k_trace<3,...>): flat, reflective (LDS frame stack)
+    and glass; whole frames only (row ranges and bands walk)."""
+    import torch
+    rng = np.random.default_rng(11)
+    u = lambda a, b: float(rng.uniform(a, b))
+    view = rtc.Matrix.make_view_transform((0.0, 2.0, -8.0), (0.0, 1.0, 5.0), (0.0, 1.0, 0.0))
+    for kind in ("flat", "reflective", "glass"):
+        w = rtc.World(rtc.light((-6.0, 9.0, -8.0)))
+        for i in range(150):
+            r = u(0.1, 0.5)
+            mat = dict(color=(u(0, 1), u(0, 1), u(0, 1)), specular=0.3, shininess=40.0)
+            if kind == "reflective" and i % 3 == 0:
+                mat["reflective"] = 0.4
+            if kind == "glass" and i % 4 == 0:
+                mat.update(transparency=0.8, refractive_index=1.5, reflective=0.2)
+            w.add_shape(rtc.sphere(rtc.Matrix.identity().scaling(r, r, r).translation(u(-7, 7), u(0.2, 4), u(-2, 20)), rtc.material(**mat)))
+        w.add_shape(rtc.sphere(rtc.Matrix.identity().scaling(5, 5, 5).translation(2, 3, 14), rtc.material(color=(0.9, 0.3, 0.2))))   # covers many tiles
+        w.add_shape(rtc.plane(rtc.Matrix.identity(), rtc.material(specular=0.0, reflective=(0.3 if kind == "reflective" else 0.0),
+                                                              pattern=("checker", (0.3,) * 3, (0.7,) * 3, None))))
+        ctx_bin, ctx_walk = _ctx_env(rtc, RTC_BIN_SMALL_PIXELS=0), _ctx_env(rtc, RTC_BINNING=0, RTC_LIGHT_LISTS=0)
+        dwb, dww = ctx_bin.upload(w), ctx_walk.upload(w)
+        for (W, H) in ((400, 232), (61, 37)):
+            cam = rtc.camera(W, H, 0.8, view)
+            for mode in (rtc.MODE_RENDER_ASYNC, rtc.MODE_RENDER):
+                a, sa = dwb.render(cam, mode, with_stats=True)
+                b, sb = dww.render(cam, mode, with_stats=True)
+                c, sc = dwb.render(cam, mode, flags=rtc.FLAG_NO_CULL, with_stats=True)
+                assert np.array_equal(a, b) and sa == sb and np.array_equal(a, c) and sa == sc, (kind, W, H, mode)
+        # several views per launch (different cameras), and the anti-aliased branch
+        cam = rtc.camera(400, 232, 0.8, view)
+        cam2 = rtc.camera(400, 232, 0.7, rtc.Matrix.make_view_transform((1.5, 2.5, -7.0), (0.0, 1.0, 5.0), (0.0, 1.0, 0.0)))
+        t = torch.zeros((3 * 232, 400, 3), dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        dwb.render_views([cam, cam2, cam], 0, 1, t.data_ptr(), 232)
+        ctx_bin.synchronize()
+        th = t.cpu().numpy()
+        assert np.array_equal(th[:232], dww.render(cam)) and np.array_equal(th[232:464], dww.render(cam2)) and np.array_equal(th[464:], th[:232])
+        cam_aa = rtc.camera(160, 96, 0.8, view, samples=3)
+        a, sa = dwb.render(cam_aa, flags=rtc.FLAG_AA_RESAMPLE, with_stats=True)
+        b, sb = dww.render(cam_aa, flags=rtc.FLAG_AA_RESAMPLE, with_stats=True)
+        assert np.array_equal(a, b) and sa == sb
+        # against the oracle on sampled pixels
+        cam = rtc.camera(400, 232, 0.8, view)
+        a = dwb.render(cam)
+        arr = w.array()
+        for _ in range(120):
+            x, y = int(rng.integers(0, 400)), int(rng.integers(0, 232))
+            want = O.color_at(arr, len(w), w.light, rtc.ray_for_pixel(cam, x, y), 5)
+            assert np.max(np.abs(a[y, x] - want)) <= TIGHT_TOL, (kind, x, y)
+        ctx_bin.close()
+        ctx_walk.close()
