@@ -403,6 +403,12 @@ DEVI double uniform_f64(double x) {
     return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
 }
 
+DEVI double lane_f64(double x, uint32_t l) { // lane l's value in every lane (l wave-uniform)
+    const unsigned long long u = __builtin_bit_cast(unsigned long long, x);
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, (int)l), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), (int)l);
+    return __builtin_bit_cast(double, ((unsigned long long)hi << 32) | lo);
+}
+
 DEVI bool finite3(V3 v) { return fabs(v.x) < __builtin_inf() && fabs(v.y) < __builtin_inf() && fabs(v.z) < __builtin_inf(); }
 
 // SHARED: every active lane's ray starts at `apex` (the camera origin, or the light for shadow
@@ -1996,17 +2002,21 @@ __global__ void __launch_bounds__(64) k_bin_tiles(const BinParams Q, const DevBo
             gmask &= gmask - 1ull;
             const uint32_t k = gsel * 64u + lane;
             bool to = false;
+            DevBound b = DevBound{0., 0., 0., __builtin_inf(), 0., 0.};
+            uint32_t entry = 0u;
             if (k < Q.n) {
-                const DevBound b = bound_s[k];
+                b = bound_s[k];
                 to = b.r < __builtin_inf() && bundle_touches(MB, b); // unbounded objects are never listed: every tile tests them anyway
+                if (to) entry = bin_entry(Q, o, b, orig_s[k]);
             }
             unsigned long long omask = ballot(to);
-            while (omask) {
-                const uint32_t ks = gsel * 64u + (uint32_t)__builtin_ctzll(omask);
+            while (omask) { // the survivor's record comes from the lane that tested it (readlane: no second round trip to memory)
+                const uint32_t l = (uint32_t)__builtin_ctzll(omask);
                 omask &= omask - 1ull;
-                const DevBound bj = bound_s[ks];
+                const DevBound bj = DevBound{lane_f64(b.cx, l), lane_f64(b.cy, l), lane_f64(b.cz, l), lane_f64(b.r, l), lane_f64(b.k, l), lane_f64(b.cn, l)};
+                const uint32_t ej = (uint32_t)__builtin_amdgcn_readlane((int)entry, (int)l);
                 if (mine && bundle_touches(TB, bj)) {
-                    if (my_cnt < RTC_TILE_LIST_CAP) my_list[my_cnt] = bin_entry(Q, o, bj, orig_s[ks]);
+                    if (my_cnt < RTC_TILE_LIST_CAP) my_list[my_cnt] = ej;
                     ++my_cnt;
                 }
             }
