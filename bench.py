@@ -34,6 +34,10 @@ import sys
 import time
 from pathlib import Path
 
+# RCCL's peer transport needs dmabuf IPC on this driver (the legacy mode fails with hipIpcGetMemHandle: invalid argument);
+# the pool exports this already — keep it set for every rank whatever launched us. Must precede the first HIP call.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = Path(__file__).resolve().parent
 sys.path[:0] = [str(ROOT), str(ROOT / "oracle")]
 
