@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define RTC_ABI_VERSION 2u
+#define RTC_ABI_VERSION 3u
 
 /* ---- status codes (the reference panics instead) -------------------- */
 typedef int32_t rtc_status;
@@ -79,6 +79,10 @@ enum { /* render flags (bit set) */
                                      documented at rtc_camera.samples (the reference draws them from thread_rng).
                                      Without this flag such pixels keep the mean of the 4 fixed sub-samples and are
                                      COUNTED in rtc_stats.pixels_resample, so the caller knows how many differ.      */
+    RTC_FLAG_LDS_TABLE = 1u << 2  /* with RTC_FLAG_NO_CULL: loop over the object table STAGED IN LDS by the workgroup (one tile
+                                     when it fits, tiles with a barrier each otherwise) instead of fetching the records through
+                                     the scalar cache — BASELINE.json north_star's literal kernel, kept for measurement
+                                     (bench.py `brute_force_lds`); identical results */
 };
 
 #define RTC_MAX_REFLECTIONS 5u /* Camera::MAX_REFLECTIONS camera.rs:31 */
@@ -253,6 +257,11 @@ void        rtc_free(void *p);
 rtc_status  rtc_canvas_write_ppm(const char *path, const double *rgb, uint32_t width, uint32_t height);
 /* The same encoder into memory: returns bytes needed (excluding NUL); writes at most cap. */
 size_t      rtc_canvas_format_ppm(const double *rgb, uint32_t width, uint32_t height, char *buf, size_t cap);
+/* The same file from a frame that is ALREADY quantised — `rgb8` = height*width*3 bytes, each Color::scale(c, 255), as
+ * rtc_render_rgb8 / rtc_render_rows' d_rgb8 deliver it: byte for byte the file rtc_canvas_write_ppm writes for the f64
+ * canvas of the same render (canvas.rs:98-104 quantises with the same function). */
+rtc_status  rtc_canvas_write_ppm_rgb8(const char *path, const uint8_t *rgb8, uint32_t width, uint32_t height);
+size_t      rtc_canvas_format_ppm_rgb8(const uint8_t *rgb8, uint32_t width, uint32_t height, char *buf, size_t cap);
 /* Color::scale(c, 255) for n colour components (color.rs:100-114) on the host. */
 void        rtc_color_scale255(const double *components, size_t n, uint8_t *out);
 /* Canvas::to_imgbuf (canvas.rs:61-79), the pixel buffer behind write_to_file / frame_to_file:
@@ -284,7 +293,9 @@ void        rtc_world_destroy(rtc_world *w);
  * without synchronising. Row-tiling hook for multi-GPU (each rank renders its rows).
  * d_rgb8 (may be NULL): additionally receives the same rows quantised to 8 bits per channel,
  * (y1-y0)*hsize*3 bytes, exactly as the reference's file writers quantise a Canvas
- * (Color::scale(c, 255): truncating saturating cast, clamp; color.rs:100-114, canvas.rs:104). */
+ * (Color::scale(c, 255): truncating saturating cast, clamp; color.rs:100-114, canvas.rs:104).
+ * d_rgb may be NULL when d_rgb8 is not: then only the 8-bit rows are written (24 B/pixel of HBM
+ * writes less); the same holds for rtc_render_bands and rtc_render_views. */
 rtc_status  rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,
                             uint32_t mode, uint32_t y0, uint32_t y1, void *d_rgb, void *d_rgb8,
                             uint32_t flags);
@@ -316,6 +327,13 @@ rtc_status  rtc_render_views(rtc_context *ctx, const rtc_world *w, const rtc_cam
  * canvas into `rgb` (vsize*hsize*3 doubles). Synchronous. `stats` may be NULL. */
 rtc_status  rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,
                        uint32_t mode, uint32_t flags, double *rgb, rtc_stats *stats);
+/* Camera::render(&World) for a caller that only WRITES THE IMAGE (every file writer of the reference consumes
+ * Color::scale'd bytes and nothing else: PPM canvas.rs:86-109, to_imgbuf canvas.rs:61-79 with gamma 1): renders all
+ * rows and copies only the 8-bit frame — vsize*hsize*3 bytes, Color::scale(c, 255) of every component, evaluated on
+ * the device bit-exactly (color.rs:100-114) — into `rgb8`: 3 bytes per pixel cross PCIe instead of 24, and the f64
+ * canvas is not even written to HBM. Feed it to rtc_canvas_write_ppm_rgb8. Synchronous. `stats` may be NULL. */
+rtc_status  rtc_render_rgb8(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,
+                            uint32_t mode, uint32_t flags, uint8_t *rgb8, rtc_stats *stats);
 /* Page-locked host memory for canvases handed to rtc_render: a canvas from rtc_host_alloc is
  * filled by one DMA at link speed, ordinary (pageable) memory goes through the runtime's bounce
  * buffers and is several times slower. What the reference would use for Canvas.pixels
@@ -327,17 +345,50 @@ rtc_status  rtc_stats_read(rtc_context *ctx, rtc_stats *out);
 rtc_status  rtc_stats_reset(rtc_context *ctx);
 /* Kernel timing. Every render launch (rtc_render_rows / _bands / _views) carries its own pair of HIP events that receive
  * the dispatch's begin and end timestamps on the context stream (hipExtLaunchKernel: no marker
- * packets, the same quantity rocprofv3's kernel trace reports) unless rtc_context_set_timing says
+ * packets, the same quantity rocprofv3's kernel trace reports FOR THE RENDER KERNEL k_trace; a launch's binning
+ * kernel is timed separately, rtc_binning_times_ms) unless rtc_context_set_timing says
  * otherwise. The context keeps the most recent 1024 pairs. rtc_kernel_times_ms writes the
  * durations (ms) of the latest min(cap, kept) launches, oldest first, and their number to *n; rtc_last_kernel_ms is the newest one alone
  * (RTC_ERR_ARG if nothing was launched yet). Both wait for the newest launch to finish. */
 rtc_status  rtc_kernel_times_ms(rtc_context *ctx, float *out, uint32_t cap, uint32_t *n);
+/* The same ring for the launches' BINNING kernels (k_bin_tiles: per-tile candidate lists, built per launch for large
+ * launches; 0 for a launch that had none): out[k] belongs to the same launch as rtc_kernel_times_ms' out[k]. The render
+ * kernel's time does not include it — in order on one stream it runs beside the PREVIOUS launch's render kernel, in a
+ * pipelined context beside the other lanes'. */
+rtc_status  rtc_binning_times_ms(rtc_context *ctx, float *out, uint32_t cap, uint32_t *n);
 /* Which launches carry an event pair: every `every`-th one (1 = all, the default; 0 = none). The
  * events cost about 9 us of host time and 5 us of GPU time per launch, which matters to callers
  * that issue many short launches (one rank's share of a frame); they sample instead. Also forgets
  * the pairs recorded so far: the next launch is the first of a new series. */
 rtc_status  rtc_context_set_timing(rtc_context *ctx, uint32_t every);
 rtc_status  rtc_last_kernel_ms(rtc_context *ctx, float *ms);
+
+/* Pipelined launches. Camera::render_async returns a NEW Canvas per call (camera.rs:144-160, Canvas::new canvas.rs:26-41),
+ * so the frames of a render loop never alias and nothing orders frame i+1 behind frame i except the caller's own use of
+ * the result. depth = 1 (the default): every render launch goes, in order, to the context's stream. depth = 2..4: the
+ * context deals consecutive launches (rtc_render_rows / _bands / _views) round-robin over `depth` streams of its own, so
+ * launch i+1 starts on the CUs that launch i's last waves leave idle (a lone 1080p launch spends a fifth of its time
+ * draining) and its per-launch binning kernel runs beside launch i's render. CONTRACT in this mode: the output buffers of
+ * `depth` consecutive launches must not overlap; launches are NOT ordered against work on the stream passed to
+ * rtc_context_create — the results are complete after rtc_context_synchronize (or rtc_stats_read), and
+ * rtc_context_fence makes that stream wait for every launch enqueued so far without blocking the host.
+ * Per pixel the results are those of depth 1, bit for bit. Synchronises before switching. [device] */
+rtc_status  rtc_context_set_pipeline(rtc_context *ctx, uint32_t depth);
+rtc_status  rtc_context_fence(rtc_context *ctx);
+/* What the most recent render launch of this context ran with (reports; the choice depends on the World's size, the
+ * launch's size and — for A/B runs only — on the RTC_* environment switches read at rtc_context_create). */
+typedef struct rtc_launch_info {
+    uint32_t source;      /* object loop: 0 brute force through the scalar cache, 1 brute force over ONE LDS-staged table,
+                             2 brute force over LDS tiles, 3 one-level per-wave cull, 4 two-level cull              */
+    uint32_t reflective;  /* frame-stack kernel (World has reflective materials)                                    */
+    uint32_t refractive;  /* ... with refraction frames                                                             */
+    uint32_t binned;      /* primary pass reads per-tile candidate lists built by the launch's binning kernel       */
+    uint32_t light_lists; /* shadow pass may use the World's light-space lists                                      */
+    uint32_t lane;        /* pipeline lane the launch went to (0 when depth = 1)                                    */
+    uint32_t block;       /* threads per workgroup                                                                  */
+    uint32_t lds_bytes;   /* dynamic LDS per workgroup (LDS-staged object tables, AA sample store)                  */
+} rtc_launch_info;
+rtc_status  rtc_context_last_launch_info(rtc_context *ctx, rtc_launch_info *out);
 
 /* Page-lock a canvas the CALLER allocated (a Rust `Vec<Color>`, canvas.rs:16-22: 24 bytes per pixel,
  * the layout rtc_render writes) so that rtc_render / rtc_group_render_host fill it by DMA at link speed
@@ -404,6 +455,24 @@ rtc_status  rtc_group_render(rtc_group *g, const rtc_group_world *w, const rtc_c
  * `stats` (may be NULL) = the local members' ray counters for this frame. */
 rtc_status  rtc_group_render_host(rtc_group *g, const rtc_group_world *w, const rtc_camera *cam, uint32_t mode,
                                   uint32_t flags, double *rgb, rtc_stats *stats);
+/* The same for the 8-bit frame (rtc_render_rgb8 across the group): `rgb8` = vsize*hsize*3 bytes. */
+rtc_status  rtc_group_render_host_rgb8(rtc_group *g, const rtc_group_world *w, const rtc_camera *cam, uint32_t mode,
+                                       uint32_t flags, uint8_t *rgb8, rtc_stats *stats);
+/* [host] The dealing of a frame's rows over the members (csrc/rtc_bands.h — the one definition rtc_group's tile sizes,
+ * gather layout, host-canvas offsets and the un-deal kernel all use), for callers that lay out their own buffers:
+ *   rtc_group_packed_rows          rows of one member's packed tile (= of one gather chunk per frame)
+ *   rtc_group_bands_owned          bands member `rank` renders: rank, rank + nranks, ...
+ *   rtc_group_row_owner            image row y -> (member, row inside its packed tile)
+ *   rtc_group_packed_row_to_image  the inverse (results >= vsize are padding)
+ *   rtc_group_undeal_host          what member 0's un-deal kernel does, on host memory: `staging` = nranks chunks of
+ *                                  [nframes][packed_rows][row_bytes] in rank order (the gather's receive buffer) ->
+ *                                  `canvas` = nframes row-major frames of vsize rows. None of these touches a GPU. */
+uint32_t    rtc_group_packed_rows(uint32_t vsize, uint32_t nranks);
+uint32_t    rtc_group_bands_owned(uint32_t vsize, uint32_t nranks, uint32_t rank);
+void        rtc_group_row_owner(uint32_t y, uint32_t nranks, uint32_t *member, uint32_t *packed_row);
+uint32_t    rtc_group_packed_row_to_image(uint32_t member, uint32_t packed_row, uint32_t nranks);
+rtc_status  rtc_group_undeal_host(const void *staging, void *canvas, uint32_t nranks, uint32_t nframes, uint32_t vsize,
+                                  size_t row_bytes);
 /* Ray counters of the local members, summed (per member: rtc_stats_read on rtc_group_context). */
 rtc_status  rtc_group_stats_read(rtc_group *g, rtc_stats *out);
 rtc_status  rtc_group_stats_reset(rtc_group *g);

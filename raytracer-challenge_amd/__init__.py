@@ -17,8 +17,8 @@ from pathlib import Path
 
 import numpy as np
 
-from .abi import (RtcCamera, RtcHit, RtcLight, RtcMaterial, RtcShape, RtcStats, Mat16, Vec3,
-                  SPHERE, PLANE, CUBE, MODE_RENDER, MODE_RENDER_ASYNC, FLAG_NONE, FLAG_NO_CULL, FLAG_AA_RESAMPLE,
+from .abi import (RtcCamera, RtcHit, RtcLaunchInfo, RtcLight, RtcMaterial, RtcShape, RtcStats, Mat16, Vec3, SOURCE_NAMES,
+                  SPHERE, PLANE, CUBE, MODE_RENDER, MODE_RENDER_ASYNC, FLAG_NONE, FLAG_NO_CULL, FLAG_AA_RESAMPLE, FLAG_LDS_TABLE,
                   EXCHANGE_RCCL, EXCHANGE_P2P, GATHER_NONE, GATHER_F64, GATHER_U8, GROUP_ID_BYTES, PATTERNS, STATUS_NAMES, declare)
 
 PKG = Path(__file__).resolve().parent
@@ -276,6 +276,23 @@ def color_scale255(rgb: np.ndarray) -> np.ndarray:
     return out
 
 
+def format_ppm_rgb8(rgb8: np.ndarray) -> bytes:
+    """The PPM of a frame that is already quantised ((H, W, 3) uint8, Color::scale'd: rtc_render_rgb8)."""
+    a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    h, w = a.shape[0], a.shape[1]
+    p = a.ctypes.data_as(C.POINTER(C.c_uint8))
+    need = lib().rtc_canvas_format_ppm_rgb8(p, w, h, None, 0)
+    buf = C.create_string_buffer(need + 1)
+    lib().rtc_canvas_format_ppm_rgb8(p, w, h, buf, need + 1)
+    return buf.raw[:need]
+
+
+def write_ppm_rgb8(path, rgb8: np.ndarray) -> None:
+    a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    _check(lib().rtc_canvas_write_ppm_rgb8(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], a.shape[0]),
+           "Canvas.write_to_file_simple (rgb8)")
+
+
 def write_ppm(path, rgb: np.ndarray) -> None:
     a = np.ascontiguousarray(rgb, dtype=np.float64)
     _check(lib().rtc_canvas_write_ppm(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_double)), a.shape[1], a.shape[0]), "Canvas.write_to_file_simple")
@@ -360,6 +377,30 @@ class Context:
         _check(lib().rtc_kernel_times_ms(self._h, buf, last, C.byref(n)), "rtc_kernel_times_ms")
         return np.frombuffer(buf, dtype=np.float32, count=n.value).copy()
 
+    def set_pipeline(self, depth: int) -> None:
+        """Deal consecutive render launches over `depth` streams of the context's own (rtc_context_set_pipeline):
+        outputs of `depth` consecutive launches must not overlap; results are complete after synchronize()."""
+        _check(lib().rtc_context_set_pipeline(self._h, depth), "rtc_context_set_pipeline")
+
+    def fence(self) -> None:
+        """Make the context's stream wait for every launch enqueued so far (no host wait)."""
+        _check(lib().rtc_context_fence(self._h), "rtc_context_fence")
+
+    def last_launch_info(self) -> dict:
+        """Object source, lists and lane the most recent render launch ran with (rtc_context_last_launch_info)."""
+        i = RtcLaunchInfo()
+        _check(lib().rtc_context_last_launch_info(self._h, C.byref(i)), "rtc_context_last_launch_info")
+        return {"source": i.source, "source_name": SOURCE_NAMES.get(i.source, "?"), "reflective": bool(i.reflective),
+                "refractive": bool(i.refractive), "binned_primary_pass": bool(i.binned), "light_lists": bool(i.light_lists),
+                "lane": i.lane, "threads_per_workgroup": i.block, "dynamic_lds_bytes": i.lds_bytes}
+
+    def binning_times_ms(self, last: int = 1024) -> np.ndarray:
+        """Durations (ms) of the binning kernels of the most recent `last` timed launches (0 where a launch had none)."""
+        buf = (C.c_float * max(1, last))()
+        n = C.c_uint32()
+        _check(lib().rtc_binning_times_ms(self._h, buf, last, C.byref(n)), "rtc_binning_times_ms")
+        return np.frombuffer(buf, dtype=np.float32, count=n.value).copy()
+
     def device_arith(self, op: int, a: np.ndarray, b: np.ndarray | None = None) -> np.ndarray:
         a = np.ascontiguousarray(a, dtype=np.float64)
         bb = np.ascontiguousarray(b if b is not None else a, dtype=np.float64)
@@ -431,6 +472,21 @@ class DeviceWorld:
             return out, _stats_dict(st, cam.samples != 1)
         return out
 
+    def render_rgb8(self, cam: RtcCamera, mode: int = MODE_RENDER_ASYNC, flags: int = 0, with_stats: bool = False,
+                    out: np.ndarray | None = None):
+        """Camera::render for a caller that only writes the image: the (vsize, hsize, 3) uint8 frame of
+        Color::scale(c, 255), quantised on the device — 3 bytes per pixel cross PCIe (rtc_render_rgb8)."""
+        if out is None:
+            out = np.empty((cam.vsize, cam.hsize, 3), dtype=np.uint8)
+        elif out.shape != (cam.vsize, cam.hsize, 3) or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous (vsize, hsize, 3) uint8 array")
+        st = RtcStats()
+        _check(lib().rtc_render_rgb8(self.ctx._h, self._h, C.byref(cam), mode, flags, out.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                     C.byref(st) if with_stats else None), "rtc_render_rgb8")
+        if with_stats:
+            return out, _stats_dict(st, cam.samples != 1)
+        return out
+
     def render_rows(self, cam: RtcCamera, y0: int, y1: int, d_ptr: int, mode: int = MODE_RENDER_ASYNC, flags: int = 0,
                     d_ptr8: int | None = None) -> None:
         """Enqueue rows [y0, y1) into the DEVICE buffer at address `d_ptr` (no synchronisation);
@@ -468,6 +524,13 @@ class DeviceWorld:
         return (rgb, hits) if want_hits else rgb
 
 
+def host_canvas_rgb8(vsize: int, hsize: int) -> np.ndarray:
+    """A zeroed (vsize, hsize, 3) uint8 frame in page-locked memory (rtc_host_alloc)."""
+    arr = np.frombuffer(_Pinned(vsize * hsize * 3).buf, dtype=np.uint8).reshape(vsize, hsize, 3)
+    arr[...] = 0
+    return arr
+
+
 def host_register(arr: np.ndarray) -> None:
     """rtc_host_register: page-lock a canvas the caller allocated (a Vec<Color> on the Rust side)."""
     _check(lib().rtc_host_register(C.c_void_p(arr.ctypes.data), arr.nbytes), "rtc_host_register")
@@ -500,7 +563,12 @@ class Group:
             _check(lib().rtc_group_create_rank(device, nranks, rank, idb, C.byref(self._h)), "rtc_group_create_rank")
         self.size = lib().rtc_group_size(self._h)
         self.local_size = lib().rtc_group_local_size(self._h)
-        self.contexts = [Context(_borrowed=lib().rtc_group_context(self._h, i)) for i in range(self.local_size)]
+        self.contexts = []
+        for i in range(self.local_size):   # member i's context, on member i's device (in-process: devices[i]; rank mode: device)
+            ptr = lib().rtc_group_context(self._h, i)
+            if not ptr:
+                raise RtcError(4, "rtc_group_context", f"member {i} has no context")
+            self.contexts.append(Context(device=(devices[i] if devices is not None else device), _borrowed=ptr))
         self._worlds = []
 
     def close(self):
@@ -575,8 +643,50 @@ class GroupWorld:
                                            C.byref(st) if with_stats else None), "rtc_group_render_host")
         return (out, _stats_dict(st, cam.samples != 1)) if with_stats else out
 
+    def render_host_rgb8(self, cam: RtcCamera, out: np.ndarray, mode: int = MODE_RENDER_ASYNC, flags: int = 0, with_stats: bool = False):
+        """The same for the 8-bit frame (Color::scale'd on the device; rtc_group_render_host_rgb8)."""
+        if out.shape != (cam.vsize, cam.hsize, 3) or out.dtype != np.uint8 or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous (vsize, hsize, 3) uint8 array")
+        st = RtcStats()
+        _check(lib().rtc_group_render_host_rgb8(self.group._h, self._h, C.byref(cam), mode, flags, out.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                C.byref(st) if with_stats else None), "rtc_group_render_host_rgb8")
+        return (out, _stats_dict(st, cam.samples != 1)) if with_stats else out
+
+
+# ---- [host] the dealing of rows over the members of a group (csrc/rtc_bands.h through the C-ABI) ------------------
+def group_packed_rows(vsize: int, nranks: int) -> int:
+    return lib().rtc_group_packed_rows(vsize, nranks)
+
+
+def group_bands_owned(vsize: int, nranks: int, rank: int) -> int:
+    return lib().rtc_group_bands_owned(vsize, nranks, rank)
+
+
+def group_row_owner(y: int, nranks: int) -> tuple[int, int]:
+    m, r = C.c_uint32(), C.c_uint32()
+    lib().rtc_group_row_owner(y, nranks, C.byref(m), C.byref(r))
+    return m.value, r.value
+
+
+def group_packed_row_to_image(member: int, packed_row: int, nranks: int) -> int:
+    return lib().rtc_group_packed_row_to_image(member, packed_row, nranks)
+
+
+def group_undeal_host(staging: np.ndarray, nranks: int, nframes: int, vsize: int) -> np.ndarray:
+    """Member 0's un-deal step on host memory: `staging` = (nranks, nframes, packed_rows, ...row) in rank order
+    (what the gather delivers) -> (nframes, vsize, ...row)."""
+    st = np.ascontiguousarray(staging)
+    rows = group_packed_rows(vsize, nranks)
+    assert st.shape[:3] == (nranks, nframes, rows), (st.shape, (nranks, nframes, rows))
+    row_bytes = int(np.prod(st.shape[3:], dtype=np.int64)) * st.itemsize
+    out = np.empty((nframes, vsize) + st.shape[3:], dtype=st.dtype)
+    _check(lib().rtc_group_undeal_host(C.c_void_p(st.ctypes.data), C.c_void_p(out.ctypes.data), nranks, nframes, vsize, row_bytes),
+           "rtc_group_undeal_host")
+    return out
+
 
 __all__ = ["lib", "RtcError", "Matrix", "material", "sphere", "plane", "cube", "light", "World", "camera", "ray_for_pixel",
            "load_yaml", "format_ppm", "write_ppm", "color_scale255", "Context", "DeviceWorld", "MODE_RENDER", "MODE_RENDER_ASYNC", "FLAG_NONE", "FLAG_NO_CULL", "FLAG_AA_RESAMPLE", "Group", "GroupWorld", "group_unique_id",
-           "host_register", "host_unregister", "EXCHANGE_RCCL", "EXCHANGE_P2P", "GATHER_NONE", "GATHER_F64", "GATHER_U8",
+           "host_register", "host_unregister", "host_canvas", "host_canvas_rgb8", "format_ppm_rgb8", "write_ppm_rgb8",
+           "group_packed_rows", "group_bands_owned", "group_row_owner", "group_packed_row_to_image", "group_undeal_host", "EXCHANGE_RCCL", "EXCHANGE_P2P", "GATHER_NONE", "GATHER_F64", "GATHER_U8",
            "SPHERE", "PLANE", "CUBE", "RtcCamera", "RtcHit", "RtcLight", "RtcMaterial", "RtcShape", "RtcStats"]

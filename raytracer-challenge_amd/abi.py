@@ -8,7 +8,7 @@ Vec3 = C.c_double * 3
 
 SPHERE, PLANE, CUBE = 0, 1, 2
 MODE_RENDER, MODE_RENDER_ASYNC = 0, 1
-FLAG_NONE, FLAG_NO_CULL, FLAG_AA_RESAMPLE = 0, 1, 2
+FLAG_NONE, FLAG_NO_CULL, FLAG_AA_RESAMPLE, FLAG_LDS_TABLE = 0, 1, 2, 4
 EXCHANGE_RCCL, EXCHANGE_P2P = 0, 1
 GATHER_NONE, GATHER_F64, GATHER_U8 = 0, 1, 2
 GROUP_ID_BYTES = 128
@@ -48,6 +48,14 @@ class RtcHit(C.Structure):
                 ("t", C.c_double), ("point", Vec3), ("over_point", Vec3), ("under_point", Vec3), ("eyev", Vec3),
                 ("normal", Vec3), ("reflectv", Vec3), ("n1", C.c_double), ("n2", C.c_double)]
 
+
+class RtcLaunchInfo(C.Structure):
+    _fields_ = [("source", C.c_uint32), ("reflective", C.c_uint32), ("refractive", C.c_uint32), ("binned", C.c_uint32),
+                ("light_lists", C.c_uint32), ("lane", C.c_uint32), ("block", C.c_uint32), ("lds_bytes", C.c_uint32)]
+
+
+SOURCE_NAMES = {0: "brute force, records through the scalar cache", 1: "brute force, object table staged in LDS (one tile)",
+                2: "brute force, object table staged in LDS tiles", 3: "one-level per-wave cull", 4: "two-level per-wave cull"}
 
 assert C.sizeof(RtcMaterial) == 264 and C.sizeof(RtcShape) == 528 and C.sizeof(RtcHit) == 184
 
@@ -97,11 +105,18 @@ PROTOTYPES = {
     "rtc_render_bands": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, U32, VP, VP, U32]),
     "rtc_render_views": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, U32, U32, VP, VP, U32, U32]),
     "rtc_render": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, PD, C.POINTER(RtcStats)]),
+    "rtc_render_rgb8": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, C.POINTER(C.c_uint8), C.POINTER(RtcStats)]),
+    "rtc_canvas_write_ppm_rgb8": (C.c_int32, [C.c_char_p, C.POINTER(C.c_uint8), U32, U32]),
+    "rtc_canvas_format_ppm_rgb8": (C.c_size_t, [C.POINTER(C.c_uint8), U32, U32, C.c_char_p, C.c_size_t]),
+    "rtc_context_set_pipeline": (C.c_int32, [VP, U32]),
+    "rtc_context_fence": (C.c_int32, [VP]),
+    "rtc_context_last_launch_info": (C.c_int32, [VP, C.POINTER(RtcLaunchInfo)]),
     "rtc_host_alloc": (C.c_int32, [C.c_size_t, C.POINTER(VP)]),
     "rtc_host_free": (None, [VP]),
     "rtc_stats_read": (C.c_int32, [VP, C.POINTER(RtcStats)]),
     "rtc_stats_reset": (C.c_int32, [VP]),
     "rtc_kernel_times_ms": (C.c_int32, [VP, C.POINTER(C.c_float), U32, C.POINTER(U32)]),
+    "rtc_binning_times_ms": (C.c_int32, [VP, C.POINTER(C.c_float), U32, C.POINTER(U32)]),
     "rtc_context_set_timing": (C.c_int32, [VP, U32]),
     "rtc_last_kernel_ms": (C.c_int32, [VP, C.POINTER(C.c_float)]),
     "rtc_host_register": (C.c_int32, [VP, C.c_size_t]),
@@ -118,6 +133,12 @@ PROTOTYPES = {
     "rtc_group_world_destroy": (None, [VP]),
     "rtc_group_render": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, U32, U32, VP, VP]),
     "rtc_group_render_host": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, PD, C.POINTER(RtcStats)]),
+    "rtc_group_render_host_rgb8": (C.c_int32, [VP, VP, C.POINTER(RtcCamera), U32, U32, C.POINTER(C.c_uint8), C.POINTER(RtcStats)]),
+    "rtc_group_packed_rows": (U32, [U32, U32]),
+    "rtc_group_bands_owned": (U32, [U32, U32, U32]),
+    "rtc_group_row_owner": (None, [U32, U32, C.POINTER(U32), C.POINTER(U32)]),
+    "rtc_group_packed_row_to_image": (U32, [U32, U32, U32]),
+    "rtc_group_undeal_host": (C.c_int32, [VP, VP, U32, U32, U32, C.c_size_t]),
     "rtc_group_stats_read": (C.c_int32, [VP, C.POINTER(RtcStats)]),
     "rtc_group_stats_reset": (C.c_int32, [VP]),
     "rtc_color_at": (C.c_int32, [VP, VP, PD, U32, U32, U32, PD, C.POINTER(RtcHit)]),

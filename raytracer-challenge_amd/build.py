@@ -46,7 +46,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     cc = hipcc()
     objdir = ROOT / "build" / "rtc"
     objdir.mkdir(parents=True, exist_ok=True)
-    headers = [ROOT / "include" / "rtc.h", CSRC / "rtc_device.h", CSRC / "rtc_internal.h"]
+    headers = [ROOT / "include" / "rtc.h", CSRC / "rtc_device.h", CSRC / "rtc_internal.h", CSRC / "rtc_bands.h"]
     objs = []
     for name in SOURCES:
         src = CSRC / name

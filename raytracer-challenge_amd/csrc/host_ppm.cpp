@@ -30,7 +30,8 @@ void append_uint(std::string &s, unsigned v) {
     while (n) s.push_back(tmp[--n]);
 }
 
-std::string encode(const double *rgb, uint32_t width, uint32_t height) {
+// `component(i)` = the i-th 8-bit component of the row-major canvas (3 per pixel)
+template <class F> std::string encode_with(uint32_t width, uint32_t height, F component) {
     std::string s;
     s.reserve(static_cast<size_t>(width) * height * 12 + 32);
     s += "P3\n";
@@ -39,17 +40,42 @@ std::string encode(const double *rgb, uint32_t width, uint32_t height) {
     append_uint(s, height);
     s += "\n255\n";
     for (uint32_t row = 0; row < height; ++row) {
-        const double *line = rgb + static_cast<size_t>(row) * width * 3;
+        const size_t line = static_cast<size_t>(row) * width * 3;
         for (uint32_t col = 0; col < width; ++col) {
             if (col) s.push_back(' ');
             for (int ch = 0; ch < 3; ++ch) {
                 if (ch) s.push_back(' ');
-                append_uint(s, static_cast<unsigned>(scale255(line[col * 3 + ch])));
+                append_uint(s, component(line + col * 3 + ch));
             }
         }
         s.push_back('\n');
     }
     return s;
+}
+
+std::string encode(const double *rgb, uint32_t width, uint32_t height) {
+    return encode_with(width, height, [rgb](size_t i) { return static_cast<unsigned>(scale255(rgb[i])); });
+}
+// the same file from components that are ALREADY Color::scale'd (the device's 8-bit frame, rtc_render_rgb8)
+std::string encode8(const uint8_t *rgb8, uint32_t width, uint32_t height) {
+    return encode_with(width, height, [rgb8](size_t i) { return static_cast<unsigned>(rgb8[i]); });
+}
+
+rtc_status write_file(const char *path, const std::string &s) {
+    std::FILE *f = std::fopen(path, "wb");
+    if (!f) return RTC_ERR_IO; // reference: panic!("Could not open output file ...") canvas.rs:87-91
+    const size_t w = std::fwrite(s.data(), 1, s.size(), f);
+    const int c = std::fclose(f);
+    return (w == s.size() && c == 0) ? RTC_OK : RTC_ERR_IO;
+}
+
+size_t copy_out(const std::string &s, char *buf, size_t cap) {
+    if (buf && cap) {
+        const size_t n = s.size() < cap ? s.size() : cap;
+        s.copy(buf, n);
+        if (n < cap) buf[n] = 0;
+    }
+    return s.size();
 }
 
 } // namespace
@@ -58,13 +84,12 @@ extern "C" {
 
 size_t rtc_canvas_format_ppm(const double *rgb, uint32_t width, uint32_t height, char *buf, size_t cap) {
     if (!rgb) return 0;
-    const std::string s = encode(rgb, width, height);
-    if (buf && cap) {
-        const size_t n = s.size() < cap ? s.size() : cap;
-        s.copy(buf, n);
-        if (n < cap) buf[n] = 0;
-    }
-    return s.size();
+    return copy_out(encode(rgb, width, height), buf, cap);
+}
+
+size_t rtc_canvas_format_ppm_rgb8(const uint8_t *rgb8, uint32_t width, uint32_t height, char *buf, size_t cap) {
+    if (!rgb8) return 0;
+    return copy_out(encode8(rgb8, width, height), buf, cap);
 }
 
 void rtc_color_scale255(const double *components, size_t n, uint8_t *out) {
@@ -86,12 +111,12 @@ void rtc_canvas_to_rgba8(const double *rgb, uint32_t width, uint32_t height, flo
 
 rtc_status rtc_canvas_write_ppm(const char *path, const double *rgb, uint32_t width, uint32_t height) {
     if (!path || !rgb) return RTC_ERR_ARG;
-    std::FILE *f = std::fopen(path, "wb");
-    if (!f) return RTC_ERR_IO; // reference: panic!("Could not open output file ...") canvas.rs:87-91
-    const std::string s = encode(rgb, width, height);
-    const size_t w = std::fwrite(s.data(), 1, s.size(), f);
-    const int c = std::fclose(f);
-    return (w == s.size() && c == 0) ? RTC_OK : RTC_ERR_IO;
+    return write_file(path, encode(rgb, width, height));
+}
+
+rtc_status rtc_canvas_write_ppm_rgb8(const char *path, const uint8_t *rgb8, uint32_t width, uint32_t height) {
+    if (!path || !rgb8) return RTC_ERR_ARG;
+    return write_file(path, encode8(rgb8, width, height));
 }
 
 } // extern "C"

@@ -35,6 +35,16 @@ struct DeviceGuard { // make ctx->device current for the calling thread
     bool ok;
 };
 
+// Pipelined context: wait for every lane (in-order contexts have none).
+hipError_t drain_lanes(rtc_context *ctx) {
+    for (uint32_t l = 0; l < rtc_context::MAX_LANES; ++l)
+        if (ctx->lane[l]) {
+            const hipError_t e = hipStreamSynchronize(ctx->lane[l]);
+            if (e != hipSuccess) return e;
+        }
+    return hipSuccess;
+}
+
 void choose_source(const rtc_context *ctx, uint32_t n, uint32_t flags, int *src, uint32_t *tile_cap, size_t *lds_bytes) {
     // per object in LDS: 96 B inverse rows + 32 B primary prologue + 4 B kind
     const uint32_t per_obj = 96 + 32 + 4;
@@ -42,6 +52,7 @@ void choose_source(const rtc_context *ctx, uint32_t n, uint32_t flags, int *src,
     if (ctx->force_src >= 0) s = ctx->force_src;
     else if (!(flags & RTC_FLAG_NO_CULL)) s = (n > 256) ? SRC_CULL2 : SRC_CULL; // default: per-wave conservative cull,
                                                                               // two-level above 4 groups of 64
+    else if (flags & RTC_FLAG_LDS_TABLE) s = SRC_LDS1; // brute force over the LDS-staged object table (LDS tiles when it does not fit)
     else if (n <= 128) s = SRC_SMEM;
     else if (n <= 448) s = SRC_LDS1;
     else s = SRC_LDSN;
@@ -249,6 +260,7 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
     if (const char *e = std::getenv("RTC_BINNING")) ctx->binning = std::atoi(e) != 0;
     if (const char *e = std::getenv("RTC_LIGHT_LISTS")) ctx->light_lists = std::atoi(e) != 0;
     if (const char *e = std::getenv("RTC_BIN_SMALL_PIXELS")) ctx->bin_small_pixels = std::strtoull(e, nullptr, 10);
+    if (const char *e = std::getenv("RTC_BIN_SMALL_PIXELS_PIPELINED")) ctx->bin_small_pixels_pipelined = std::strtoull(e, nullptr, 10);
     if (const char *e = std::getenv("RTC_TILE_CAP")) {
         const int v = std::atoi(e);
         if (v >= 16 && v <= 1024) ctx->tile_cap = (uint32_t)v;
@@ -261,10 +273,18 @@ void rtc_context_destroy(rtc_context *ctx) {
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    (void)drain_lanes(ctx);
+    for (hipStream_t &l : ctx->lane)
+        if (l) { (void)hipStreamDestroy(l); l = nullptr; }
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     if (ctx->d_canvas) (void)hipFree(ctx->d_canvas);
+    if (ctx->d_canvas8) (void)hipFree(ctx->d_canvas8);
     if (ctx->side_stream) { (void)hipStreamSynchronize(ctx->side_stream); (void)hipStreamDestroy(ctx->side_stream); }
+    if (ctx->fence_ev) (void)hipEventDestroy(ctx->fence_ev);
     for (auto &pair : ctx->ev)
+        for (hipEvent_t e : pair)
+            if (e) (void)hipEventDestroy(e);
+    for (auto &pair : ctx->ev_bin)
         for (hipEvent_t e : pair)
             if (e) (void)hipEventDestroy(e);
     delete ctx;
@@ -273,7 +293,42 @@ void rtc_context_destroy(rtc_context *ctx) {
 rtc_status rtc_context_synchronize(rtc_context *ctx) {
     if (!ctx) return RTC_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(drain_lanes(ctx));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return RTC_OK;
+}
+
+rtc_status rtc_context_set_pipeline(rtc_context *ctx, uint32_t depth) {
+    if (!ctx || depth == 0 || depth > rtc_context::MAX_LANES) return RTC_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(drain_lanes(ctx));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (ctx->side_stream) HIP_TRY(hipStreamSynchronize(ctx->side_stream));
+    if (depth > 1)
+        for (uint32_t l = 0; l < depth; ++l)
+            if (!ctx->lane[l]) HIP_TRY(hipStreamCreateWithFlags(&ctx->lane[l], hipStreamNonBlocking));
+    ctx->lanes = depth;
+    ctx->lane_next = 0;
+    return RTC_OK;
+}
+
+rtc_status rtc_context_fence(rtc_context *ctx) {
+    if (!ctx) return RTC_ERR_ARG;
+    if (ctx->lanes <= 1) return RTC_OK; // in order on the stream already
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->fence_ev) HIP_TRY(hipEventCreateWithFlags(&ctx->fence_ev, hipEventDisableTiming));
+    for (uint32_t l = 0; l < rtc_context::MAX_LANES; ++l)
+        if (ctx->lane[l]) {
+            HIP_TRY(hipEventRecord(ctx->fence_ev, ctx->lane[l]));
+            HIP_TRY(hipStreamWaitEvent(ctx->stream, ctx->fence_ev, 0)); // (the wait captures the record made just above)
+        }
+    return RTC_OK;
+}
+
+rtc_status rtc_context_last_launch_info(rtc_context *ctx, rtc_launch_info *out) {
+    if (!ctx || !out) return RTC_ERR_ARG;
+    if (ctx->launches_total == 0) return RTC_ERR_ARG; // nothing launched yet
+    *out = ctx->last;
     return RTC_OK;
 }
 
@@ -549,27 +604,85 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
         // Camera::resample traces `antialiasing_samples` more rays (camera.rs:87); u8 in the reference
         P.resample_n = (flags & RTC_FLAG_AA_RESAMPLE) ? (cam->samples & 0xffu) : 0u;
     }
-    // binned primary pass (two-level worlds, tile rows aligned with the image's): three small kernels put
-    // every object on the list of each 8x8 tile its bounding sphere can touch (same conservative predicate as the wave-level
-    // cull), so the render kernel's primary pass runs exact tests on a short list instead of walking the groups. Two-level
-    // worlds always; one-level worlds when the launch is long enough (bin_small_pixels) and covers whole frames (one rank's
-    // share of a 100-object frame renders faster than the frame's binning).
+    // start/stop events cost ~9 us of host time and ~5 us of GPU time per launch (measured): callers
+    // that are launch-bound sample every n-th launch instead (rtc_context_set_timing)
+    const bool timed = ctx->time_every != 0 && ctx->launches % ctx->time_every == 0;
+    const uint32_t slot = (uint32_t)(ctx->timed % rtc_context::EV_RING);
+    if (timed && slot >= ctx->ev_created) { // next chunk of the ring
+        const uint32_t upto = std::min<uint32_t>(rtc_context::EV_RING, ctx->ev_created + rtc_context::EV_CHUNK);
+        for (uint32_t k = ctx->ev_created; k < upto; ++k) {
+            HIP_TRY(hipEventCreate(&ctx->ev[k][0]));
+            HIP_TRY(hipEventCreate(&ctx->ev[k][1]));
+            HIP_TRY(hipEventCreate(&ctx->ev_bin[k][0]));
+            HIP_TRY(hipEventCreate(&ctx->ev_bin[k][1]));
+            ctx->ev_created = k + 1;
+        }
+    }
+    hipEvent_t *pair = ctx->ev[slot], *pair_bin = ctx->ev_bin[slot];
+    if (timed) ctx->bin_timed[slot] = false;
+    // Which stream. A pipelined context deals the launches round-robin over its lanes; the brute-force variants share one
+    // per-render table (w->d_prim) and stay in order on lane 0.
+    const bool piped = ctx->lanes > 1;
+    const uint32_t lane = piped ? ((src == SRC_CULL || src == SRC_CULL2) ? (uint32_t)(ctx->lane_next++ % ctx->lanes) : 0u) : 0u;
+    hipStream_t stream = piped ? ctx->lane[lane] : ctx->stream;
+    // the part of the frame this launch renders, in pixels (a rank's bands: its share)
+    const unsigned long long launch_pixels = (unsigned long long)nviews * cam->hsize * std::min<unsigned long long>((unsigned long long)grid_y * 8u, cam->vsize);
+    // binned primary pass (tile rows aligned with the image's): one small kernel puts every object on the list of each 8x8
+    // tile its bounding sphere can touch (same conservative predicate as the wave-level cull), so the render kernel's primary
+    // pass runs exact tests on a short list instead of walking the groups. Two-level worlds always; one-level worlds when the
+    // launch is long enough for the extra kernel (and, in order on one stream, its two cross-stream events) to pay:
+    // bin_small_pixels counts the pixels THIS launch renders — whole frames or one rank's bands (k_bin_tiles lists only the
+    // tile rows the launch renders).
     const bool bin_this = (src == SRC_CULL2) ||
-                          (src == SRC_CULL && (unsigned long long)nviews * cam->hsize * cam->vsize >= ctx->bin_small_pixels &&
-                           band_stride == 1u && y0 == 0u && y1 == cam->vsize);
+                          (src == SRC_CULL && (piped ? launch_pixels >= ctx->bin_small_pixels_pipelined
+                                                     : launch_pixels >= ctx->bin_small_pixels));
     rtc_world::BinSet *binset = nullptr;
-    if (bin_this && ctx->binning && (y0 % 8u) == 0u && w->n != 0u) {
-        const uint32_t tiles_x = (cam->hsize + 7u) / 8u, tiles_y = (cam->vsize + 7u) / 8u;
-        const size_t tiles = (size_t)tiles_x * tiles_y * nviews;
+    bool bin_ok = bin_this && ctx->binning && (y0 % 8u) == 0u && w->n != 0u;
+    const uint32_t tiles_x = (cam->hsize + 7u) / 8u, tiles_y = (cam->vsize + 7u) / 8u;
+    const size_t tiles = (size_t)tiles_x * tiles_y * nviews;
+    if (bin_ok && piped) {
+        // lane-local lists: the binning kernel precedes the render kernel on the lane's own stream and runs beside the other
+        // lanes' render kernels — no events. Sized for the largest launch seen (grow-only; growing waits for the lane).
+        rtc_world::BinSet &B = w->bin[lane];
+        if (B.tiles_cap < tiles) {
+            (void)hipStreamSynchronize(stream);
+            if (B.tile_cnt) (void)hipFree(B.tile_cnt);
+            if (B.tile_list) (void)hipFree(B.tile_list);
+            B.tile_cnt = nullptr; B.tile_list = nullptr; B.tiles_cap = 0;
+            ++ctx->render_allocs;
+            const bool got = hipMalloc(&B.tile_cnt, sizeof(uint32_t) * tiles) == hipSuccess &&
+                             (++ctx->render_allocs, hipMalloc(&B.tile_list, sizeof(uint32_t) * tiles * RTC_TILE_LIST_CAP) == hipSuccess);
+            if (got) B.tiles_cap = tiles;
+            else { // the lists are an optimisation: without memory for them the launch walks (same pixels)
+                if (B.tile_cnt) (void)hipFree(B.tile_cnt);
+                B.tile_cnt = nullptr; B.tile_list = nullptr;
+                (void)hipGetLastError();
+                bin_ok = false;
+            }
+        }
+        if (bin_ok) {
+            HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound_s, w->d_gbound, w->d_orig_s, w->ngroups, B.tile_cnt,
+                                       B.tile_list, y0 / 8u, band_stride, stream, timed ? pair_bin[0] : nullptr, timed ? pair_bin[1] : nullptr));
+            if (timed) ctx->bin_timed[slot] = true;
+            P.tile_cnt = B.tile_cnt;
+            P.tile_list = B.tile_list;
+            P.tiles_x = tiles_x;
+            P.tiles_y = tiles_y;
+            P.bin_packed = RTC_BIN_PACKED(w->n) ? 1u : 0u;
+            P.n_unb = w->n_unb;
+        }
+    } else if (bin_ok) {
         if (!ctx->side_stream) HIP_TRY(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-        // Capacity. Both sets are made ready by the FIRST binned launch, and for RTC_MAX_VIEWS views whenever that stays small
-        // (1080p: 67 MB per set; exactly the launch's views otherwise): a launch sequence must not allocate after its first
-        // launch — hipMalloc / hipFree wait for the device, 0.2-3 ms in the middle of a frame sequence (a 5-frame warm-up
-        // launch followed by 8-frame launches did exactly that: 0.09-0.22 ms per frame instead of 0.07).
+        // Capacity. Both sets are made ready by the FIRST binned launch, and for RTC_MAX_VIEWS views while that stays within
+        // 128 MB per set (1080p: 67 MB; larger frames: exactly the launch's views, growing once if a later launch has more): a
+        // launch sequence must not allocate after its first launch — hipMalloc / hipFree wait for the device, 0.2-3 ms in the
+        // middle of a frame sequence (a 5-frame warm-up launch followed by 8-frame launches did exactly that: 0.09-0.22 ms per
+        // frame instead of 0.07). The lists are an optimisation: when there is no memory for them the launch walks instead.
         const size_t per_view_bytes = (size_t)tiles_x * tiles_y * sizeof(uint32_t) * (1u + RTC_TILE_LIST_CAP);
-        const uint32_t alloc_views = per_view_bytes <= ((size_t)128 << 20) ? (uint32_t)RTC_MAX_VIEWS : nviews;
+        const uint32_t alloc_views = per_view_bytes * RTC_MAX_VIEWS <= ((size_t)128 << 20) ? (uint32_t)RTC_MAX_VIEWS : nviews;
         const size_t tiles_alloc = (size_t)tiles_x * tiles_y * alloc_views;
-        for (rtc_world::BinSet &S : w->bin) {
+        for (uint32_t k = 0; k < 2u && bin_ok; ++k) {
+            rtc_world::BinSet &S = w->bin[k];
             if (!S.binned) {
                 HIP_TRY(hipEventCreateWithFlags(&S.binned, hipEventDisableTiming));
                 HIP_TRY(hipEventCreateWithFlags(&S.traced, hipEventDisableTiming));
@@ -579,18 +692,28 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
                 if (S.tile_list) (void)hipFree(S.tile_list);
                 S.tile_cnt = nullptr; S.tile_list = nullptr;
                 S.tiles_cap = 0;
-                ++ctx->render_allocs; HIP_TRY(hipMalloc(&S.tile_cnt, sizeof(uint32_t) * tiles_alloc));
-                ++ctx->render_allocs; HIP_TRY(hipMalloc(&S.tile_list, sizeof(uint32_t) * tiles_alloc * RTC_TILE_LIST_CAP));
-                S.tiles_cap = tiles_alloc;
+                ++ctx->render_allocs;
+                const bool got = hipMalloc(&S.tile_cnt, sizeof(uint32_t) * tiles_alloc) == hipSuccess &&
+                                 (++ctx->render_allocs, hipMalloc(&S.tile_list, sizeof(uint32_t) * tiles_alloc * RTC_TILE_LIST_CAP) == hipSuccess);
+                if (got) S.tiles_cap = tiles_alloc;
+                else {
+                    if (S.tile_cnt) (void)hipFree(S.tile_cnt);
+                    S.tile_cnt = nullptr; S.tile_list = nullptr;
+                    (void)hipGetLastError();
+                    bin_ok = false;
+                }
             }
         }
+    }
+    if (bin_ok && !piped) {
         rtc_world::BinSet &B = w->bin[w->bin_next++ & 1u];
         // The binning depends on the World (resident since rtc_world_create) and on this launch's cameras only, so it goes
         // to the side stream: it runs beside the PREVIOUS launch's render kernel, which still reads the other set. It must
         // wait for the render kernel that last read THIS set (two launches ago); the render stream waits for the binning.
         HIP_TRY(hipStreamWaitEvent(ctx->side_stream, B.traced, 0)); // never recorded: no wait
         HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound_s, w->d_gbound, w->d_orig_s, w->ngroups, B.tile_cnt,
-                                   B.tile_list, y0 / 8u, band_stride, ctx->side_stream));
+                                   B.tile_list, y0 / 8u, band_stride, ctx->side_stream, timed ? pair_bin[0] : nullptr, timed ? pair_bin[1] : nullptr));
+        if (timed) ctx->bin_timed[slot] = true;
         HIP_TRY(hipEventRecord(B.binned, ctx->side_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, B.binned, 0));
         P.tile_cnt = B.tile_cnt;
@@ -602,23 +725,13 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
         binset = &B;
     }
     // per-render prologue table of the brute-force variants (the culled kernels do not use it)
-    if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.views[0].vinv, ctx->stream));
-    // start/stop events cost ~9 us of host time and ~5 us of GPU time per launch (measured): callers
-    // that are launch-bound sample every n-th launch instead (rtc_context_set_timing)
-    const bool timed = ctx->time_every != 0 && ctx->launches % ctx->time_every == 0;
-    const uint32_t slot = (uint32_t)(ctx->timed % rtc_context::EV_RING);
-    if (timed && slot >= ctx->ev_created) { // next chunk of the ring
-        const uint32_t upto = std::min<uint32_t>(rtc_context::EV_RING, ctx->ev_created + rtc_context::EV_CHUNK);
-        for (uint32_t k = ctx->ev_created; k < upto; ++k) {
-            HIP_TRY(hipEventCreate(&ctx->ev[k][0]));
-            HIP_TRY(hipEventCreate(&ctx->ev[k][1]));
-            ctx->ev_created = k + 1;
-        }
-    }
-    hipEvent_t *pair = ctx->ev[slot];
-    HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y * nviews, lds_bytes, ctx->stream,
+    if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.views[0].vinv, stream));
+    HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x * P.grid_y * nviews, lds_bytes, stream,
                              timed ? pair[0] : nullptr, timed ? pair[1] : nullptr));
     if (binset) HIP_TRY(hipEventRecord(binset->traced, ctx->stream));
+    ctx->last = rtc_launch_info{(uint32_t)src, (w->any_refl || w->any_refr) ? 1u : 0u, w->any_refr ? 1u : 0u, P.tile_cnt ? 1u : 0u,
+                                P.light_cnt ? 1u : 0u, lane, block, (uint32_t)lds_bytes};
+    ++ctx->launches_total;
     // rtc_stats::pixels is known here (the kernel traces exactly the pixels of this launch's rows; Camera::render leaves the
     // last row and column alone, camera.rs:120-121): counted on the host, one atomic per wave less
     {
@@ -640,7 +753,7 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
 
 rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode, uint32_t y0,
                            uint32_t y1, void *d_rgb, void *d_rgb8, uint32_t flags) {
-    if (!ctx || !w || !cam || !d_rgb || w->ctx != ctx) return RTC_ERR_ARG;
+    if (!ctx || !w || !cam || (!d_rgb && !d_rgb8) || w->ctx != ctx) return RTC_ERR_ARG;
     if (mode > RTC_MODE_RENDER_ASYNC || cam->hsize == 0 || cam->vsize == 0 || y0 > y1 || y1 > cam->vsize) return RTC_ERR_ARG;
     if (cam->samples > 255u) return RTC_ERR_ARG; // antialiasing_samples is a u8 (camera.rs:24)
     if (y0 == y1) return RTC_OK;
@@ -649,7 +762,7 @@ rtc_status rtc_render_rows(rtc_context *ctx, const rtc_world *w, const rtc_camer
 
 rtc_status rtc_render_bands(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode,
                             uint32_t first_band, uint32_t band_stride, void *d_rgb, void *d_rgb8, uint32_t flags) {
-    if (!ctx || !w || !cam || !d_rgb || w->ctx != ctx) return RTC_ERR_ARG;
+    if (!ctx || !w || !cam || (!d_rgb && !d_rgb8) || w->ctx != ctx) return RTC_ERR_ARG;
     if (mode > RTC_MODE_RENDER_ASYNC || cam->hsize == 0 || cam->vsize == 0 || band_stride == 0) return RTC_ERR_ARG;
     if (cam->samples > 255u) return RTC_ERR_ARG;
     const uint32_t nbands = (cam->vsize + RTC_BAND_ROWS - 1u) / RTC_BAND_ROWS;
@@ -662,6 +775,7 @@ rtc_status rtc_stats_read(rtc_context *ctx, rtc_stats *out) {
     if (!ctx || !out) return RTC_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     std::vector<unsigned long long> slots((size_t)CNT_N * CNT_SLOTS);
+    HIP_TRY(drain_lanes(ctx));
     HIP_TRY(hipMemcpyAsync(slots.data(), ctx->d_counters, sizeof(unsigned long long) * slots.size(), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     unsigned long long h[CNT_N] = {0};
@@ -704,7 +818,9 @@ extern "C" rtc_status rtc_debug_render_allocs(rtc_context *ctx, unsigned long lo
 rtc_status rtc_stats_reset(rtc_context *ctx) {
     if (!ctx) return RTC_ERR_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(drain_lanes(ctx));
     HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * CNT_N * CNT_SLOTS, ctx->stream));
+    if (ctx->lanes > 1) HIP_TRY(hipStreamSynchronize(ctx->stream)); // the lanes are not ordered behind the stream
     ctx->pixels = 0;
     return RTC_OK;
 }
@@ -732,6 +848,22 @@ rtc_status rtc_kernel_times_ms(rtc_context *ctx, float *out, uint32_t cap, uint3
     return RTC_OK;
 }
 
+rtc_status rtc_binning_times_ms(rtc_context *ctx, float *out, uint32_t cap, uint32_t *n) {
+    if (!ctx || !n || (cap && !out)) return RTC_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const uint64_t have = ctx->timed < rtc_context::EV_RING ? ctx->timed : rtc_context::EV_RING;
+    const uint64_t take = have < cap ? have : cap;
+    *n = (uint32_t)take;
+    if (take == 0) return RTC_OK;
+    HIP_TRY(hipEventSynchronize(ctx->ev[(ctx->timed - 1) % rtc_context::EV_RING][1])); // the render kernel follows its binning
+    for (uint64_t k = 0; k < take; ++k) {
+        const uint64_t sl = (ctx->timed - take + k) % rtc_context::EV_RING;
+        out[k] = 0.f;
+        if (ctx->bin_timed[sl]) HIP_TRY(hipEventElapsedTime(&out[k], ctx->ev_bin[sl][0], ctx->ev_bin[sl][1]));
+    }
+    return RTC_OK;
+}
+
 rtc_status rtc_last_kernel_ms(rtc_context *ctx, float *ms) {
     uint32_t n = 0;
     if (!ctx || !ms) return RTC_ERR_ARG;
@@ -745,7 +877,7 @@ static_assert(RTC_MAX_VIEWS == RTC_MAX_VIEWS_PER_LAUNCH, "include/rtc.h and rtc_
 rtc_status rtc_render_views(rtc_context *ctx, const rtc_world *w, const rtc_camera *cams, uint32_t nviews, uint32_t mode,
                             uint32_t first_band, uint32_t band_stride, void *d_rgb, void *d_rgb8, uint32_t view_rows,
                             uint32_t flags) {
-    if (!ctx || !w || !cams || !d_rgb || w->ctx != ctx) return RTC_ERR_ARG;
+    if (!ctx || !w || !cams || (!d_rgb && !d_rgb8) || w->ctx != ctx) return RTC_ERR_ARG;
     if (nviews == 0 || nviews > RTC_MAX_VIEWS_PER_LAUNCH || band_stride == 0 || mode > RTC_MODE_RENDER_ASYNC) return RTC_ERR_ARG;
     if (cams[0].hsize == 0 || cams[0].vsize == 0) return RTC_ERR_ARG;
     for (uint32_t v = 1; v < nviews; ++v)
@@ -764,7 +896,7 @@ rtc_status rtc_render_views(rtc_context *ctx, const rtc_world *w, const rtc_came
         // the brute-force variants keep a per-render table of the camera origin in object space: one view per launch
         for (uint32_t v = 0; v < nviews; ++v) {
             const rtc_status st = render_launch(ctx, w, cams + v, mode, first_band * RTC_BAND_ROWS, cams[0].vsize, band_stride, mine,
-                                                static_cast<double *>(d_rgb) + (size_t)v * view_rows * cams[0].hsize * 3u,
+                                                d_rgb ? static_cast<double *>(d_rgb) + (size_t)v * view_rows * cams[0].hsize * 3u : nullptr,
                                                 d_rgb8 ? static_cast<unsigned char *>(d_rgb8) + (size_t)v * view_rows * cams[0].hsize * 3u : nullptr,
                                                 flags);
             if (st != RTC_OK) return st;
@@ -785,16 +917,45 @@ rtc_status rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *ca
         if (ctx->d_canvas) (void)hipFree(ctx->d_canvas);
         ctx->d_canvas = nullptr;
         ctx->canvas_bytes = 0;
-        ++ctx->render_allocs; HIP_TRY(hipMalloc(&ctx->d_canvas, bytes));
+        ++ctx->render_allocs;
+        const hipError_t e = hipMalloc(&ctx->d_canvas, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? RTC_ERR_NOMEM : RTC_ERR_DEVICE; }
         ctx->canvas_bytes = bytes;
     }
     double *d = ctx->d_canvas;
     rtc_status st = RTC_OK;
     if (stats) st = rtc_stats_reset(ctx);
     if (st == RTC_OK) st = rtc_render_rows(ctx, w, cam, mode, 0, cam->vsize, d, nullptr, flags);
+    if (st == RTC_OK && drain_lanes(ctx) != hipSuccess) st = RTC_ERR_DEVICE; // pipelined context: the copy below is on the stream
     // `rgb` from rtc_host_alloc (page-locked) is filled by one DMA at link speed; pageable memory
     // goes through the runtime's bounce buffers (several times slower)
     if (st == RTC_OK && hipMemcpyAsync(rgb, d, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
+    if (st == RTC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
+    if (st == RTC_OK && stats) st = rtc_stats_read(ctx, stats);
+    return st;
+}
+
+rtc_status rtc_render_rgb8(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam, uint32_t mode, uint32_t flags,
+                           uint8_t *rgb8, rtc_stats *stats) {
+    if (!ctx || !w || !cam || !rgb8 || w->ctx != ctx) return RTC_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t bytes = (size_t)3 * cam->hsize * cam->vsize;
+    if (bytes == 0) return RTC_ERR_ARG;
+    if (ctx->canvas8_bytes < bytes) { // grow-only, like rtc_render's f64 scratch
+        if (ctx->d_canvas8) (void)hipFree(ctx->d_canvas8);
+        ctx->d_canvas8 = nullptr;
+        ctx->canvas8_bytes = 0;
+        ++ctx->render_allocs;
+        const hipError_t e = hipMalloc(&ctx->d_canvas8, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); return e == hipErrorOutOfMemory ? RTC_ERR_NOMEM : RTC_ERR_DEVICE; }
+        ctx->canvas8_bytes = bytes;
+    }
+    rtc_status st = RTC_OK;
+    if (stats) st = rtc_stats_reset(ctx);
+    // only the 8-bit rows leave the kernel: no f64 canvas is written (d_rgb = NULL)
+    if (st == RTC_OK) st = rtc_render_rows(ctx, w, cam, mode, 0, cam->vsize, nullptr, ctx->d_canvas8, flags);
+    if (st == RTC_OK && drain_lanes(ctx) != hipSuccess) st = RTC_ERR_DEVICE;
+    if (st == RTC_OK && hipMemcpyAsync(rgb8, ctx->d_canvas8, bytes, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
     if (st == RTC_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) st = RTC_ERR_DEVICE;
     if (st == RTC_OK && stats) st = rtc_stats_read(ctx, stats);
     return st;

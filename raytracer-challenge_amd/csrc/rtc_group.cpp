@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "rtc.h"
+#include "rtc_bands.h"
 #include "rtc_device.h"
 #include "rtc_internal.h"
 
@@ -145,10 +146,11 @@ template <class T> rtc_status grow(T *&p, size_t &cap, size_t bytes) {
     return RTC_OK;
 }
 
-uint32_t bands_of(uint32_t vsize) { return (vsize + RTC_BAND_ROWS - 1u) / RTC_BAND_ROWS; }
-// rows of one member's packed tile: the most bands any member owns, 8 rows each (the same for all
-// members, so that the gather's chunks are equal)
-uint32_t packed_rows(uint32_t vsize, uint32_t nranks) { return ((bands_of(vsize) + nranks - 1u) / nranks) * RTC_BAND_ROWS; }
+static_assert(RTC_BANDS_ROWS == RTC_BAND_ROWS, "rtc_bands.h and include/rtc.h disagree");
+// the dealing of bands over members lives in rtc_bands.h (shared with k_undeal and the [host] entries below)
+uint32_t bands_of(uint32_t vsize) { return rtc_bands_of(vsize); }
+uint32_t packed_rows(uint32_t vsize, uint32_t nranks) { return rtc_packed_rows(vsize, nranks); }
+uint32_t bands_owned(uint32_t vsize, uint32_t nranks, uint32_t rank) { return rtc_bands_owned(vsize, nranks, rank); }
 
 } // namespace
 
@@ -295,14 +297,14 @@ void rtc_group_world_destroy(rtc_group_world *w) {
 // One launch per local member: its bands of `nframes` frames into tile buffer `b` (after the exchange that
 // last read that buffer); the member's exchange stream is made to wait for the launch.
 static rtc_status render_members(rtc_group *g, const rtc_group_world *w, const rtc_camera *cams, uint32_t nframes, uint32_t mode,
-                                 uint32_t flags, bool want8, int b) {
+                                 uint32_t flags, bool want8, int b, bool want64 = true) {
     const uint32_t W = cams[0].hsize, H = cams[0].vsize, N = g->nranks;
     const uint32_t rows = packed_rows(H, N);
     const size_t tile_bytes = (size_t)nframes * rows * W * 3u * sizeof(double), tile8_bytes = (size_t)nframes * rows * W * 3u;
     for (size_t i = 0; i < g->m.size(); ++i) {
         Member &mb = g->m[i];
         HIP_TRY(hipSetDevice(mb.device));
-        if (mb.tile_cap < tile_bytes) { // both buffers grow together (hipFree waits for the device)
+        if (want64 && mb.tile_cap < tile_bytes) { // both buffers grow together (hipFree waits for the device)
             size_t c0 = mb.tile[0] ? mb.tile_cap : 0, c1 = mb.tile[1] ? mb.tile_cap : 0;
             rtc_status st = grow(mb.tile[0], c0, tile_bytes);
             if (st == RTC_OK) st = grow(mb.tile[1], c1, tile_bytes);
@@ -317,7 +319,7 @@ static rtc_status render_members(rtc_group *g, const rtc_group_world *w, const r
             mb.tile8_cap = tile8_bytes;
         }
         HIP_TRY(hipStreamWaitEvent(mb.s_render, mb.sent[b], 0)); // an event never recorded does not block
-        const rtc_status st = rtc_render_views(mb.ctx, w->w[i], cams, nframes, mode, mb.rank, N, mb.tile[b],
+        const rtc_status st = rtc_render_views(mb.ctx, w->w[i], cams, nframes, mode, mb.rank, N, want64 ? mb.tile[b] : nullptr,
                                                want8 ? mb.tile8[b] : nullptr, rows, flags);
         if (st != RTC_OK) return st;
         HIP_TRY(hipEventRecord(mb.rendered[b], mb.s_render));
@@ -425,14 +427,47 @@ rtc_status rtc_group_render_host(rtc_group *g, const rtc_group_world *w, const r
     for (Member &mb : g->m) {
         if (mb.rank >= nb) continue;
         HIP_TRY(hipSetDevice(mb.device));
-        const uint32_t mine = (nb - mb.rank + N - 1u) / N;
+        const uint32_t mine = bands_owned(H, N, mb.rank);
         const bool last_short = (H % RTC_BAND_ROWS) != 0 && (mb.rank + (mine - 1u) * N) == nb - 1u;
         const uint32_t whole = last_short ? mine - 1u : mine;
-        char *dst = reinterpret_cast<char *>(rgb) + (size_t)mb.rank * band_bytes;
+        char *dst = reinterpret_cast<char *>(rgb) + (size_t)rtc_packed_row_to_image(mb.rank, 0u, N) * row_bytes; // = rank * band_bytes
         if (whole)
             HIP_TRY(hipMemcpy2DAsync(dst, (size_t)N * band_bytes, mb.tile[b], band_bytes, band_bytes, whole, hipMemcpyDeviceToHost, mb.s_comm));
         if (last_short)
             HIP_TRY(hipMemcpyAsync(dst + (size_t)whole * N * band_bytes, reinterpret_cast<char *>(mb.tile[b]) + (size_t)whole * band_bytes,
+                                   (size_t)(H % RTC_BAND_ROWS) * row_bytes, hipMemcpyDeviceToHost, mb.s_comm));
+        HIP_TRY(hipEventRecord(mb.sent[b], mb.s_comm));
+    }
+    st = rtc_group_synchronize(g);
+    if (st == RTC_OK && stats) st = rtc_group_stats_read(g, stats);
+    return st;
+}
+
+rtc_status rtc_group_render_host_rgb8(rtc_group *g, const rtc_group_world *w, const rtc_camera *cam, uint32_t mode, uint32_t flags,
+                                      uint8_t *rgb8, rtc_stats *stats) {
+    if (!g || !w || !cam || !rgb8 || w->g != g || w->w.size() != g->m.size()) return RTC_ERR_ARG;
+    const uint32_t W = cam->hsize, H = cam->vsize, N = g->nranks;
+    if (W == 0 || H == 0) return RTC_ERR_ARG;
+    if (cam->samples > 255u) return RTC_ERR_ARG;
+    const int b = (int)(g->batches & 1u);
+    rtc_status st = RTC_OK;
+    if (stats) st = rtc_group_stats_reset(g);
+    if (st == RTC_OK) st = render_members(g, w, cam, 1, mode, flags, true, b, false); // 8-bit rows only
+    if (st != RTC_OK) return st;
+    ++g->batches;
+    const size_t row_bytes = (size_t)W * 3u, band_bytes = row_bytes * RTC_BAND_ROWS;
+    const uint32_t nb = bands_of(H);
+    for (Member &mb : g->m) { // band k of member r = image rows (r + k*N)*8 ..: one strided DMA per member, as for the f64 canvas
+        if (mb.rank >= nb) continue;
+        HIP_TRY(hipSetDevice(mb.device));
+        const uint32_t mine = bands_owned(H, N, mb.rank);
+        const bool last_short = (H % RTC_BAND_ROWS) != 0 && (mb.rank + (mine - 1u) * N) == nb - 1u;
+        const uint32_t whole = last_short ? mine - 1u : mine;
+        unsigned char *dst = rgb8 + (size_t)mb.rank * band_bytes;
+        if (whole)
+            HIP_TRY(hipMemcpy2DAsync(dst, (size_t)N * band_bytes, mb.tile8[b], band_bytes, band_bytes, whole, hipMemcpyDeviceToHost, mb.s_comm));
+        if (last_short)
+            HIP_TRY(hipMemcpyAsync(dst + (size_t)whole * N * band_bytes, mb.tile8[b] + (size_t)whole * band_bytes,
                                    (size_t)(H % RTC_BAND_ROWS) * row_bytes, hipMemcpyDeviceToHost, mb.s_comm));
         HIP_TRY(hipEventRecord(mb.sent[b], mb.s_comm));
     }
@@ -455,6 +490,27 @@ rtc_status rtc_group_stats_read(rtc_group *g, rtc_stats *out) {
         out->pixels += s.pixels;
         out->pixels_resample += s.pixels_resample;
     }
+    return RTC_OK;
+}
+
+// ---- [host] the dealing itself, for callers that lay out their own buffers and for the CPU tests ----------------
+uint32_t rtc_group_packed_rows(uint32_t vsize, uint32_t nranks) { return nranks ? rtc_packed_rows(vsize, nranks) : 0u; }
+uint32_t rtc_group_bands_owned(uint32_t vsize, uint32_t nranks, uint32_t rank) { return nranks ? rtc_bands_owned(vsize, nranks, rank) : 0u; }
+void rtc_group_row_owner(uint32_t y, uint32_t nranks, uint32_t *member, uint32_t *packed_row) {
+    if (!nranks || !member || !packed_row) return;
+    rtc_row_owner(y, nranks, member, packed_row);
+}
+uint32_t rtc_group_packed_row_to_image(uint32_t member, uint32_t packed_row, uint32_t nranks) {
+    return nranks ? rtc_packed_row_to_image(member, packed_row, nranks) : 0u;
+}
+rtc_status rtc_group_undeal_host(const void *staging, void *canvas, uint32_t nranks, uint32_t nframes, uint32_t vsize, size_t row_bytes) {
+    if (!staging || !canvas || nranks == 0) return RTC_ERR_ARG;
+    const uint32_t rows_max = rtc_packed_rows(vsize, nranks);
+    const unsigned char *src = static_cast<const unsigned char *>(staging);
+    unsigned char *dst = static_cast<unsigned char *>(canvas);
+    for (uint32_t f = 0; f < nframes; ++f)
+        for (uint32_t y = 0; y < vsize; ++y) // k_undeal with one unit per row: the same index function (rtc_bands.h)
+            std::memcpy(dst + ((size_t)f * vsize + y) * row_bytes, src + rtc_staging_index(f, y, 0u, nranks, nframes, rows_max, 1u) * row_bytes, row_bytes);
     return RTC_OK;
 }
 

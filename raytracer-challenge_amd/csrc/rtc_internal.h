@@ -23,6 +23,8 @@ struct rtc_context {
     // rtc_context_create the slowest call of a one-frame render)
     static constexpr uint32_t EV_RING = 1024, EV_CHUNK = 16;
     hipEvent_t ev[EV_RING][2] = {};
+    hipEvent_t ev_bin[EV_RING][2] = {}; // the same for the launch's binning kernel (k_bin_tiles), when it has one
+    bool bin_timed[EV_RING] = {};       // ... whether slot k's launch had one
     uint32_t ev_created = 0; // pairs [0, ev_created) exist
     uint64_t launches = 0; // render launches so far
     uint64_t timed = 0;    // ... of which carried an event pair (ring position)
@@ -30,9 +32,23 @@ struct rtc_context {
     // device canvas of rtc_render (host-canvas entry point): grow-only, reused between frames
     double *d_canvas = nullptr;
     size_t canvas_bytes = 0;
+    unsigned char *d_canvas8 = nullptr; // the same for rtc_render_rgb8 (3 B/pixel)
+    size_t canvas8_bytes = 0;
     int force_src = -1;   // RTC_SRC env override (experiments)
     uint32_t tile_cap = 512;
     hipStream_t side_stream = nullptr; // created on demand: per-render binning kernels run here, beside the previous launch's render
+    // Pipelined launches (rtc_context_set_pipeline, include/rtc.h): `lanes` > 1 deals consecutive render launches round-robin
+    // over that many streams of the context's own, so launch i+1 fills the CUs launch i's last waves leave idle (Camera::
+    // render_async returns a NEW Canvas per call, canvas.rs:26-41: consecutive frames never alias). A lane is in order:
+    // [k_bin_tiles ->] k_trace, its own set of tile lists (rtc_world::bin[lane]), no cross-stream events at all.
+    static constexpr uint32_t MAX_LANES = 4;
+    hipStream_t lane[MAX_LANES] = {};
+    uint32_t lanes = 1;       // 1 = every launch in order on `stream` (the default)
+    uint64_t lane_next = 0;   // launches dealt so far
+    // the source / lists the most recent render launch ran with (rtc_context_last_launch_info)
+    rtc_launch_info last{};
+    uint64_t launches_total = 0; // render launches since the context was created (never reset)
+    hipEvent_t fence_ev = nullptr; // rtc_context_fence
     bool light_lists = true; // RTC_LIGHT_LISTS=0: shadow passes of two-level worlds walk the groups (A/B)
     bool binning = true;  // RTC_BINNING=0: primary rays take the wave-level cull / group walk too (A/B)
     // one-level worlds (<= 256 objects) are binned only in launches of at least this many views (RTC_BIN_SMALL_VIEWS): the
@@ -43,6 +59,9 @@ struct rtc_context {
     // one-level worlds (n <= 256) are binned when the launch is long enough for the extra kernel and its two cross-stream
     // events to pay: views x pixels >= this (RTC_BIN_SMALL_PIXELS; 1080p: from 3 views per launch, 4096^2: always)
     unsigned long long bin_small_pixels = 6000000ull;
+    // ... and in a pipelined context (lanes > 1), where the binning kernel of launch i+1 runs beside launch i's render on the
+    // other lane without any event: from this many pixels (RTC_BIN_SMALL_PIXELS_PIPELINED)
+    unsigned long long bin_small_pixels_pipelined = 1500000ull;
 };
 
 struct rtc_world {
@@ -68,7 +87,7 @@ struct rtc_world {
         hipEvent_t binned = nullptr;     // recorded on the side stream after the set's binning kernel
         hipEvent_t traced = nullptr;     // recorded on the render stream after the render kernel that read the set
     };
-    mutable BinSet bin[2];
+    mutable BinSet bin[rtc_context::MAX_LANES]; // in-order contexts alternate between [0] and [1]; a pipelined context's lane l owns [l]
     mutable uint32_t bin_next = 0;
     // light-space shadow lists (two-level worlds), built once at rtc_world_create
     DevTileBundle *d_light_cells = nullptr;
@@ -84,7 +103,7 @@ struct rtc_world {
 
 extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound_s,
                                          const DevBound *gbound, const uint32_t *orig_s, uint32_t ngroups, uint32_t *cnt, uint32_t *list,
-                                         uint32_t row0, uint32_t row_stride, hipStream_t stream);
+                                         uint32_t row0, uint32_t row_stride, hipStream_t stream, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 extern "C" hipError_t rtc_launch_light_lists(uint32_t n, uint32_t cap, const DevBound *bound, const double light[3], double reach, DevTileBundle *cells,
                                              DevTileBundle *macros, uint32_t *cnt, uint32_t *list, hipStream_t stream);
 extern "C" hipError_t rtc_launch_undeal(const void *staging, void *canvas, uint32_t nranks, uint32_t nframes, uint32_t H,

@@ -28,6 +28,7 @@
 #include <hip/hip_ext.h>
 
 #include "rtc.h"
+#include "rtc_bands.h"
 #include "rtc_device.h"
 
 // Depth of the reflection / refraction frame stack. A frame is pushed only by a color_at call whose
@@ -1422,7 +1423,9 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             bool listed = false;
             if constexpr (SRC == SRC_CULL) {
                 const auto &Pl = KP(P_arg);
-                if (Pl.light_cnt != nullptr && ballot(hit) != 0ull && ballot(hit && !(sdist <= Pl.light_reach)) == 0ull) {
+                // (Pl.n <= 256: the "done" set below has one bit per object; a larger World only gets here with the one-level
+                // cull FORCED, RTC_SRC=3, and then takes the bundle walk)
+                if (Pl.light_cnt != nullptr && Pl.n <= 256u && ballot(hit) != 0ull && ballot(hit && !(sdist <= Pl.light_reach)) == 0ull) {
                     const uint32_t cid = hit ? light_cell(vneg(sdir)) : 0u;
                     listed = true;
                     uint32_t ncells = 0;
@@ -1754,7 +1757,8 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 const double *src = stage_f64 + wave * 24u;
                 // a row of the wave's part is 192 contiguous bytes of the canvas: 12 pieces of 16 bytes
                 const bool wide = cols == 8u && (row_bytes % 16u) == 0 && ((size_t)Po.out % 16u) == 0;
-                if (wide) {
+                if (Po.out == nullptr) { // 8-bit frame only (rtc_render_rgb8): nothing of the f64 canvas leaves the chip
+                } else if (wide) {
                     typedef double __attribute__((ext_vector_type(2))) d2;
                     for (uint32_t c = lane; c < rows * 12u; c += 64u) {
                         const uint32_t r = c / 12u, k = c % 12u;
@@ -1796,7 +1800,8 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 // f64 canvas: 16-byte pieces when every tile row is whole and 16-byte aligned
                 const size_t row_bytes = (size_t)Po.W * 24u;
                 const bool wide = cols == TILE_W && (row_bytes % 16u) == 0 && ((size_t)Po.out % 16u) == 0;
-                if (wide) {
+                if (Po.out == nullptr) { // 8-bit frame only (rtc_render_rgb8)
+                } else if (wide) {
                     typedef double __attribute__((ext_vector_type(2))) d2;
                     for (uint32_t c = threadIdx.x; c < rows * (TILE_W * 3u / 2u); c += BLOCK) {
                         const uint32_t r = c / (TILE_W * 3u / 2u), k = c % (TILE_W * 3u / 2u);
@@ -2027,7 +2032,7 @@ __global__ void __launch_bounds__(64) k_bin_tiles(const BinParams Q, const DevBo
 
 extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound_s,
                                          const DevBound *gbound, const uint32_t *orig_s, uint32_t ngroups, uint32_t *cnt, uint32_t *list,
-                                         uint32_t row0, uint32_t row_stride, hipStream_t stream) {
+                                         uint32_t row0, uint32_t row_stride, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
     if (n == 0) return hipSuccess;
     BinParams Q;
     Q.row0 = row0; Q.row_stride = row_stride ? row_stride : 1u;
@@ -2037,7 +2042,8 @@ extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews
     Q.packed = RTC_BIN_PACKED(n) ? 1u : 0u;
     Q.tiles_x = (W + 7u) / 8u; Q.tiles_y = (H + 7u) / 8u;
     Q.macros_x = (Q.tiles_x + 7u) / 8u; Q.macros_y = (Q.tiles_y + 7u) / 8u;
-    hipLaunchKernelGGL(k_bin_tiles, dim3(nviews * Q.macros_x * Q.macros_y), dim3(64), 0, stream, Q, bound_s, gbound, orig_s, ngroups, cnt, list);
+    // e0/e1 (may be NULL): the dispatch's own begin/end timestamps, as for k_trace
+    hipExtLaunchKernelGGL(k_bin_tiles, dim3(nviews * Q.macros_x * Q.macros_y), dim3(64), 0, stream, e0, e1, 0, Q, bound_s, gbound, orig_s, ngroups, cnt, list);
     return hipGetLastError();
 }
 
@@ -2137,8 +2143,7 @@ __global__ void __launch_bounds__(256) k_undeal(const U *__restrict__ staging, U
         const uint32_t u = (uint32_t)(i % row_units);
         const size_t fy = i / row_units;
         const uint32_t y = (uint32_t)(fy % H), f = (uint32_t)(fy / H);
-        const uint32_t band = y / 8u, p = band % nranks, k = band / nranks;
-        canvas[i] = staging[(((size_t)p * nframes + f) * rows_max + k * 8u + (y & 7u)) * row_units + u];
+        canvas[i] = staging[rtc_staging_index(f, y, u, nranks, nframes, rows_max, row_units)]; // rtc_bands.h: THE mapping
     }
 }
 

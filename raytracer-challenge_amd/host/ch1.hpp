@@ -152,14 +152,22 @@ class Canvas { // canvas.rs:16-109
   public:
     uint32_t width, height;
     std::vector<double> pixels; // [y][x][rgb], idx = y*width + x (canvas.rs:44)
+    // A Canvas returned by Camera::render_rgb8 / render_async_rgb8 holds ONLY what the reference's file writers read from a
+    // Canvas — Color::scale(c, 255) of every component (canvas.rs:98-104, color.rs:100-114), evaluated on the device: 3 bytes
+    // per pixel crossed PCIe instead of 24 and `pixels` is empty. write_to_file_simple writes the same file either way.
+    std::vector<uint8_t> rgb8;
     Canvas(uint32_t w, uint32_t h) : width(w), height(h), pixels(static_cast<size_t>(w) * h * 3, 0.0) {} // BLACK canvas.rs:37-41
+    static Canvas quantised(uint32_t w, uint32_t h) { Canvas c(0, 0); c.width = w; c.height = h; c.rgb8.assign(static_cast<size_t>(w) * h * 3, 0); return c; }
+    bool is_quantised() const { return pixels.empty() && !rgb8.empty(); }
     void write_pixel(uint32_t x, uint32_t y, Color c) { double *p = at(x, y); p[0] = c.red; p[1] = c.green; p[2] = c.blue; }
     Color get_pixel(uint32_t x, uint32_t y) const { const double *p = const_cast<Canvas *>(this)->at(x, y); return {p[0], p[1], p[2]}; }
     void write_to_file_simple(const std::string &file_name) const { // canvas.rs:86-109
-        check(rtc_canvas_write_ppm(file_name.c_str(), pixels.data(), width, height), "Canvas::write_to_file_simple");
+        if (is_quantised()) check(rtc_canvas_write_ppm_rgb8(file_name.c_str(), rgb8.data(), width, height), "Canvas::write_to_file_simple");
+        else check(rtc_canvas_write_ppm(file_name.c_str(), pixels.data(), width, height), "Canvas::write_to_file_simple");
     }
   private:
     double *at(uint32_t x, uint32_t y) {
+        if (is_quantised()) throw std::logic_error("Canvas holds the 8-bit frame only (Camera::render_rgb8): render() for f64 pixels");
         if (x >= width || y >= height) throw std::out_of_range("Canvas index out of bounds");
         return pixels.data() + (static_cast<size_t>(y) * width + x) * 3;
     }
@@ -286,6 +294,10 @@ class Camera { // camera.rs:17-160
     Canvas render(const World &w) const { return run(w, RTC_MODE_RENDER); }             // camera.rs:116-126
     Canvas render_async(const World &w) const { return run(w, RTC_MODE_RENDER_ASYNC); } // camera.rs:144-160
     Canvas render_async1(const World &w) const { return run(w, RTC_MODE_RENDER_ASYNC); } // camera.rs:128-142
+    // The same renders for a caller that only writes the image (jamis.rs / main.rs: render, then write_to_file*): the Canvas
+    // comes back quantised (Canvas::rgb8), see Canvas.
+    Canvas render_rgb8(const World &w) const { return run8(w, RTC_MODE_RENDER); }
+    Canvas render_async_rgb8(const World &w) const { return run8(w, RTC_MODE_RENDER_ASYNC); }
 
   private:
     Canvas run(const World &w, uint32_t mode) const {
@@ -294,6 +306,14 @@ class Camera { // camera.rs:17-160
         Canvas canvas(hsize, vsize);
         World::Uploaded up(w);
         check(rtc_render(Device::get(), up.w, &c, mode, RTC_FLAG_NONE, canvas.pixels.data(), nullptr), "Camera::render");
+        return canvas;
+    }
+    Canvas run8(const World &w, uint32_t mode) const {
+        rtc_camera c = flat_;
+        c.samples = antialiasing_samples;
+        Canvas canvas = Canvas::quantised(hsize, vsize);
+        World::Uploaded up(w);
+        check(rtc_render_rgb8(Device::get(), up.w, &c, mode, RTC_FLAG_NONE, canvas.rgb8.data(), nullptr), "Camera::render");
         return canvas;
     }
     rtc_camera flat_{};

@@ -102,7 +102,16 @@ static void criterion_scene(const std::string &ppm_path) { // benches/render.rs:
     double sum = 0.;
     for (double v : canvas.pixels) sum += v;
     EXPECT(sum > 1000.);
-    if (!ppm_path.empty()) canvas.write_to_file_simple(ppm_path);
+    if (!ppm_path.empty()) {
+        canvas.write_to_file_simple(ppm_path);
+        // the quantised Canvas (only the device's 8-bit frame crossed PCIe) writes the same file, byte for byte
+        Canvas q = camera.render_async_rgb8(world);
+        EXPECT(q.is_quantised() && q.pixels.empty() && q.rgb8.size() == 400u * 300u * 3u);
+        q.write_to_file_simple(ppm_path + ".rgb8");
+        bool threw = false;
+        try { (void)q.get_pixel(0, 0); } catch (const std::logic_error &) { threw = true; }
+        EXPECT(threw);
+    }
 }
 
 static void test_panics() {

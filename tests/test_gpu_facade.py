@@ -23,6 +23,8 @@ def test_reference_style_cpp_tests_on_gpu(tmp_path, rtc, O):
     w, cam = scenes.criterion(400, 300)
     want = O.format_ppm(O.render(w.array(), len(w), w.light, cam, mode=1, nthreads=8))
     assert ppm.read_bytes() == want
+    # ... and so does the file written from the quantised Canvas (Camera::render_async_rgb8 -> rtc_render_rgb8)
+    assert (tmp_path / "criterion.ppm.rgb8").read_bytes() == want
 
 
 def test_facade_compiles_against_the_library():

@@ -372,30 +372,30 @@ def test_empty_world_and_error_paths(rtc, gpu):
 @pytest.mark.parametrize("H", [90, 93, 5])
 def test_interleaved_bands_compose_the_frame(rtc, gpu, scenes, H):
     """rtc_render_bands: for N = 1, 2, 3, 8 the packed bands of all `ranks`, un-dealt with
-    tiles.deinterleave, are the full frame bit for bit (f64 and 8-bit), and the ray counts add up."""
+    rtc_group_undeal_host, are the full frame bit for bit (f64 and 8-bit), and the ray counts add up."""
     import torch
-    tiles = importlib.import_module(rtc.__name__ + ".tiles")
+    
     w, cam = scenes.synthetic(25, 160, H)
     dw = gpu.upload(w)
     full, st_full = dw.render(cam, rtc.MODE_RENDER_ASYNC, with_stats=True)
     full8 = rtc.color_scale255(full).reshape(full.shape)
     for N in (1, 2, 3, 8):
-        per = tiles.packed_rows(H, N)
-        gathered = torch.full((N * per, 160, 3), -1.0, dtype=torch.float64, device="cuda:0")
-        gathered8 = torch.full((N * per, 160, 3), 77, dtype=torch.uint8, device="cuda:0")
+        per = rtc.group_packed_rows(H, N)
+        gathered = torch.full((N, 1, per, 160, 3), -1.0, dtype=torch.float64, device="cuda:0")   # the gather's layout: rank-major chunks
+        gathered8 = torch.full((N, 1, per, 160, 3), 77, dtype=torch.uint8, device="cuda:0")
         gpu.reset_stats()
         for r in range(N):
-            dw.render_bands(cam, r, N, gathered[r * per:].data_ptr(), d_ptr8=gathered8[r * per:].data_ptr())
+            dw.render_bands(cam, r, N, gathered[r].data_ptr(), d_ptr8=gathered8[r].data_ptr())
         st = gpu.stats()
         assert st == st_full, (N, st, st_full)
-        canvas = tiles.deinterleave(gathered, torch.empty_like(gathered), N)
-        canvas8 = tiles.deinterleave(gathered8, torch.empty_like(gathered8), N)
-        assert np.array_equal(canvas[:H].cpu().numpy(), full), N
-        assert np.array_equal(canvas8[:H].cpu().numpy(), full8), N
+        canvas = rtc.group_undeal_host(gathered.cpu().numpy(), N, 1, H)[0]     # the product's un-deal arithmetic (csrc/rtc_bands.h)
+        canvas8 = rtc.group_undeal_host(gathered8.cpu().numpy(), N, 1, H)[0]
+        assert np.array_equal(canvas, full), N
+        assert np.array_equal(canvas8, full8), N
         # slots beyond the bands a rank owns are never written
         for r in range(N):
-            used = 8 * len(tiles.bands_of_rank(H, N, r))
-            assert (gathered[r * per + used:(r + 1) * per] == -1.0).all()
+            used = 8 * rtc.group_bands_owned(H, N, r)
+            assert (gathered[r, 0, used:] == -1.0).all()
     with pytest.raises(rtc.RtcError):
         dw.render_bands(cam, 0, 0, gathered.data_ptr())
     dw.close()
@@ -404,8 +404,8 @@ def test_interleaved_bands_compose_the_frame(rtc, gpu, scenes, H):
 @pytest.mark.parametrize("extra", [["--exchange", "f64"], ["--exchange", "u8", "--views-per-launch", "3"], ["--exchange", "none"]])
 def test_bench_group_path_with_one_rank(extra):
     """bench.py's multi-GPU path (rtc_group in rank mode: RCCL communicator from a broadcast id, ncclGather per
-    batch, un-deal kernel, shared host canvas) with a single rank: the frame member 0 assembles must equal a plain
-    render; the line carries the contract keys and the secondary exchange records."""
+    call, un-deal kernel, shared host canvases f64 + 8-bit) with a single rank: the frame member 0 assembles must equal a
+    plain render (checked whatever the exchange); the line carries the contract keys and the secondary records."""
     import json
     import subprocess
     import sys
@@ -416,34 +416,56 @@ def test_bench_group_path_with_one_rank(extra):
                        capture_output=True, text=True, timeout=300, env=env, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    if "none" not in extra:
-        assert line["config"]["gathered_frame_vs_single_gpu_render"] == "ok"
-    assert line["dropin"]["shared_canvas_vs_single_gpu_render"] == "ok"
+    assert line["config"]["gathered_frame_vs_single_gpu_render"] == "ok"
+    h = line["host_canvas"]
+    assert h["shared_canvas_vs_single_gpu_render"] == "ok" and "error" not in h
+    assert h["rtc_group_render_host_ms"] > 0 and h["rtc_group_render_host_rgb8_ms"] > 0
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "launch"):
         assert key in line
     assert line["steps"] == 11 and line["n_gpus"] == 1 and 1 <= line["roofline"]["kernel_launches_timed"] <= 11
     assert sum(k.startswith("exchange_") for k in line) == 2 and line["roofline"]["frac"] < 1
+    assert ("batched_views" in line) == ("--views-per-launch" not in extra)
 
 
-def test_bench_single_gpu_line_is_robust_to_ragged_steps():
-    """--steps not a multiple of the frames per launch (the driver runs --steps 20 with 8 frames per launch): the roofline
-    averages full-size launches only, per-frame kernel time is reported, single_view and dropin records are present."""
+def test_bench_single_gpu_line():
+    """The driver's command shape (--steps 20 --warmup 5) at a small size: the headline is ONE camera per launch on a pipelined
+    context; the roofline comes from the solo leg; the labelled secondary records, the launch record and both drop-in paths
+    (f64 and 8-bit) are present; the brute-force LDS record carries the flops fraction."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "20", "--warmup", "3", "--no-cpu-baseline",
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-cpu-baseline",
                         "--width", "640", "--height", "360"], capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["frames_per_launch"] == 1 and line["config"]["pipeline_streams"] == 2 and "ONE camera" in line["config"]["call_shape"]
     rf = line["roofline"]
-    assert rf["frames_per_launch"] == 8 and rf["kernel_launches_timed"] == 3 and rf["kernel_launches_of_full_size"] == 2
-    assert abs(rf["kernel_ms_avg"] / 8 - rf["kernel_ms_per_frame"]) < 0.5 * rf["kernel_ms_per_frame"] and 0 < rf["frac"] < 1
-    assert line["single_view"]["frames_per_launch"] == 1 and line["single_view"]["value"] > 0
+    assert rf["frames_per_launch"] == 1 and rf["kernel_launches_timed"] == 24 and 0 < rf["frac"] < 1
+    assert rf["algorithmic_bytes_per_launch"] == 24 * 640 * 360 + 400 * 101 + 128 + 200
+    assert line["launch"]["source"] == 3 and line["launch"]["threads_per_workgroup"] == 128
+    assert line["serial_single_view"]["value"] > 0 and line["serial_single_view"]["launch"]["lane"] == 0
+    assert line["batched_views"]["frames_per_launch"] == 8 and line["batched_views"]["value"] > 0
+    bf = line["brute_force_lds"]
+    assert bf["launch"]["source"] == 1 and bf["launch"]["dynamic_lds_bytes"] >= 101 * 132 and 0 < bf["f64_valu"]["frac"] < 1
+    assert bf["kernel_ms_per_frame"] > line["roofline"]["kernel_ms_per_frame"]
     d = line["dropin"]
     assert d["context_create_ms"] < 5 and d["rtc_render_pinned_ms"] <= d["rtc_render_pageable_ms"] * 1.5
-    assert "valu_roofline" not in line
+    assert d["rgb8_equals_color_scale_of_the_f64_canvas"] is True and 0 < d["rtc_render_rgb8_ms"] < d["rtc_render_pinned_ms"]
+    assert "valu_roofline" not in line and "single_view" not in line
+    # a batch is available, labelled as such
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "1", "--lean", "--views-per-launch", "4",
+                        "--width", "320", "--height", "180"], capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["config"]["frames_per_launch"] == 4 and "batch" in line["config"]["call_shape"]
+    # the roofline leg alone (what rocprofv3 wraps)
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "6", "--profile-leg", "--width", "320", "--height", "180"],
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["profile_leg"] and line["launches"] == 6 and line["kernel_ms_avg"] > 0
 
 
 @pytest.mark.parametrize("reflective", [False, True])
@@ -452,7 +474,7 @@ def test_views_of_one_launch_equal_separate_renders(rtc, gpu, scenes, reflective
     reference's AddFrame loop does, lua.rs) == the same cameras rendered one by one, bit for bit
     (f64 canvas, 8-bit frame, ray counts); whole frames and one rank's bands; brute-force fallback."""
     import torch
-    tiles = importlib.import_module(rtc.__name__ + ".tiles")
+    
     W, H = 160, 93
     w, _ = scenes.synthetic(25, W, H, reflective=reflective)
     cams = [rtc.camera(W, H, 0.7 + 0.05 * i, rtc.Matrix.make_view_transform((3.0 * math.sin(0.4 * i), 2.0, -8.0 + i), (0.0, 1.0, 5.0), (0.0, 1.0, 0.0)))
@@ -467,7 +489,7 @@ def test_views_of_one_launch_equal_separate_renders(rtc, gpu, scenes, reflective
     assert not np.array_equal(singles[0], singles[1])
     for flags in (0, 1):
         # whole frames: first_band 0, stride 1; views stacked with 4 spare rows between them
-        rows = tiles.n_bands(H) * 8 + 4
+        rows = (-(-H // 8)) * 8 + 4
         f = torch.full((5 * rows, W, 3), -1.0, dtype=torch.float64, device="cuda:0")
         q = torch.full((5 * rows, W, 3), 9, dtype=torch.uint8, device="cuda:0")
         gpu.reset_stats()
@@ -477,10 +499,10 @@ def test_views_of_one_launch_equal_separate_renders(rtc, gpu, scenes, reflective
         for v in range(5):
             assert np.array_equal(fh[v * rows: v * rows + H], singles[v]), (flags, v)
             assert np.array_equal(qh[v * rows: v * rows + H], rtc.color_scale255(singles[v]).reshape(H, W, 3)), (flags, v)
-            assert (fh[v * rows + tiles.n_bands(H) * 8: (v + 1) * rows] == -1.0).all()
+            assert (fh[v * rows + (-(-H // 8)) * 8: (v + 1) * rows] == -1.0).all()
     # one rank's bands (rank 1 of 3) of every view
     N, r = 3, 1
-    per = tiles.packed_rows(H, N)
+    per = rtc.group_packed_rows(H, N)
     f = torch.zeros((5 * per, W, 3), dtype=torch.float64, device="cuda:0")
     dw.render_views(cams, r, N, f.data_ptr(), per)
     one = torch.zeros((per, W, 3), dtype=torch.float64, device="cuda:0")

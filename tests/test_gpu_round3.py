@@ -1,0 +1,237 @@
+"""GPU tests of the round-3 additions to the C-ABI: pipelined launches (rtc_context_set_pipeline), the host-side 8-bit
+delivery (rtc_render_rgb8, rtc_group_render_host_rgb8, rtc_canvas_*_ppm_rgb8), rtc_context_last_launch_info, the
+LDS-table brute force by flag, and the forced one-level cull beyond 256 objects."""
+import importlib
+import math
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def scenes(rtc):
+    return importlib.import_module(rtc.__name__ + ".scenes")
+
+
+def _ctx_env(rtc, **env):
+    old = {k: os.environ.get(k) for k in env}
+    try:
+        for k, v in env.items():
+            os.environ[k] = str(v)
+        return rtc.Context(0)
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.mark.parametrize("kind", ["flat100", "reflective", "glass", "large"])
+def test_pipelined_launches_equal_in_order_launches(rtc, scenes, kind):
+    """rtc_context_set_pipeline(2..4): consecutive launches on alternating streams of the context's own, each with its own
+    tile lists in front of it — canvases, 8-bit frames and ray counts must be those of the in-order context bit for bit,
+    for one camera per launch (distinct cameras, a ring of canvases), for bands, and with the lists forced on and off."""
+    import torch
+    W, H = 320, 203
+    if kind == "flat100":
+        w, _ = scenes.synthetic(100, W, H)
+    elif kind == "reflective":
+        w, _ = scenes.synthetic(60, W, H, reflective=True)
+    elif kind == "glass":
+        w, _ = scenes.glass_cluster(40, W, H)
+    else:
+        w, _ = scenes.synthetic(700, W, H, with_plane=True)
+    cams = [rtc.camera(W, H, 0.7 + 0.03 * i, rtc.Matrix.make_view_transform((2.5 * math.sin(0.3 * i), 2.0, -8.0 + 0.5 * i), (0.0, 1.0, 5.0), (0.0, 1.0, 0.0)))
+            for i in range(7)]
+    ref_ctx = rtc.Context(0)
+    dref = ref_ctx.upload(w)
+    want, total = [], {}
+    for c in cams:
+        img, st = dref.render(c, rtc.MODE_RENDER_ASYNC, with_stats=True)
+        want.append(img)
+        for k, v in st.items():
+            total[k] = total.get(k, 0) + v
+    dref.close()
+    ref_ctx.close()
+    for depth, small in ((2, 0), (3, 10**12), (4, 0)):   # lists forced for every launch / never (one-level worlds)
+        ctx = _ctx_env(rtc, RTC_BIN_SMALL_PIXELS_PIPELINED=small)
+        dw = ctx.upload(w)
+        ctx.set_pipeline(depth)
+        ring = [torch.full((H, W, 3), -1.0, dtype=torch.float64, device="cuda:0") for _ in range(len(cams))]
+        ring8 = [torch.full((H, W, 3), 7, dtype=torch.uint8, device="cuda:0") for _ in range(len(cams))]
+        torch.cuda.synchronize()
+        ctx.reset_stats()
+        lanes = []
+        for i, c in enumerate(cams):
+            dw.render_rows(c, 0, H, ring[i].data_ptr(), rtc.MODE_RENDER_ASYNC, d_ptr8=ring8[i].data_ptr())
+            info = ctx.last_launch_info()
+            lanes.append(info["lane"])
+            assert info["binned_primary_pass"] == (kind == "large" or small == 0), (kind, depth, info)
+        assert lanes == [i % depth for i in range(len(cams))]
+        assert ctx.stats() == total, (kind, depth)        # synchronises every lane
+        for i in range(len(cams)):
+            assert np.array_equal(ring[i].cpu().numpy(), want[i]), (kind, depth, i)
+            assert np.array_equal(ring8[i].cpu().numpy(), rtc.color_scale255(want[i]).reshape(H, W, 3)), (kind, depth, i)
+        # one rank's bands through the pipelined context (rank 1 of 3), and the fence: work on the caller's stream afterwards
+        per = rtc.group_packed_rows(H, 3)
+        tiles = [torch.zeros((per, W, 3), dtype=torch.float64, device="cuda:0") for _ in range(3)]
+        torch.cuda.synchronize()
+        for i in range(3):
+            dw.render_bands(cams[i], 1, 3, tiles[i].data_ptr())
+        ctx.fence()
+        ctx.synchronize()
+        for i in range(3):
+            got = tiles[i].cpu().numpy()
+            for k in range(rtc.group_bands_owned(H, 3, 1)):
+                y0 = rtc.group_packed_row_to_image(1, 8 * k, 3)
+                y1 = min(H, y0 + 8)
+                assert np.array_equal(got[8 * k: 8 * k + (y1 - y0)], want[i][y0:y1]), (kind, depth, i, k)
+        # back to in-order launches on the same context and World
+        ctx.set_pipeline(1)
+        one = torch.zeros((H, W, 3), dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()
+        dw.render_rows(cams[3], 0, H, one.data_ptr(), rtc.MODE_RENDER_ASYNC)
+        ctx.synchronize()
+        assert np.array_equal(one.cpu().numpy(), want[3])
+        assert np.array_equal(dw.render(cams[5]), want[5])   # rtc_render (host canvas) on a context that was pipelined
+        dw.close()
+        ctx.close()
+    with pytest.raises(rtc.RtcError):
+        c = rtc.Context(0)
+        try:
+            c.set_pipeline(5)
+        finally:
+            c.close()
+
+
+def test_rgb8_delivery_and_ppm_equal_the_f64_path_and_the_oracle(rtc, gpu, scenes, O, tmp_path):
+    """rtc_render_rgb8 (only the device's 8-bit frame crosses PCIe; no f64 canvas is written) == Color::scale of the f64 render,
+    and the PPM written from it == rtc_canvas_format_ppm of the f64 render == the PPM of the oracle's canvas
+    (canvas.rs:86-109, color.rs:100-114), for Camera::render and render_async, AA on, odd sizes (the unaligned store path)."""
+    for (name, W, H, samples) in (("mixed", 160, 120, 1), ("mixed", 50, 37, 1), ("test8", 96, 72, 4), ("default", 33, 9, 1)):
+        if name == "mixed":
+            w, cam = scenes.mixed(W, H)
+        elif name == "test8":
+            w, cam = scenes.test8(W, H, samples=samples)
+        else:
+            w, cam = scenes.default_scene(W, H)
+        dw = gpu.upload(w)
+        for mode in (rtc.MODE_RENDER, rtc.MODE_RENDER_ASYNC):
+            f64, st64 = dw.render(cam, mode, with_stats=True)
+            u8, st8 = dw.render_rgb8(cam, mode, with_stats=True)
+            assert st8 == st64
+            assert u8.dtype == np.uint8 and u8.shape == (H, W, 3)
+            assert np.array_equal(u8, rtc.color_scale255(f64).reshape(H, W, 3)), (name, W, H, mode)
+            ppm8 = rtc.format_ppm_rgb8(u8)
+            assert ppm8 == rtc.format_ppm(f64)
+            want = O.render(w.array(), len(w), w.light, cam, mode=mode)
+            assert np.max(np.abs(want - f64)) <= 1e-12
+            # the oracle's PPM: identical unless a component sits within 1e-12 of a quantisation step (pow is <= 4 ulp)
+            oppm = O.format_ppm(want) if hasattr(O, "format_ppm") else rtc.format_ppm(want)
+            if oppm != ppm8:
+                a = np.frombuffer(rtc.color_scale255(want).tobytes(), dtype=np.uint8).reshape(H, W, 3).astype(int)
+                d = np.abs(a - u8.astype(int))
+                assert d.max() <= 1 and (d != 0).sum() <= 3, (name, W, H, mode, int(d.max()), int((d != 0).sum()))
+            p = tmp_path / f"{name}_{W}_{mode}.ppm"
+            rtc.write_ppm_rgb8(p, u8)
+            assert p.read_bytes() == ppm8
+        # a page-locked 8-bit frame, reused
+        pin = rtc.host_canvas_rgb8(H, W)
+        dw.render_rgb8(cam, out=pin)
+        assert np.array_equal(pin, rtc.color_scale255(dw.render(cam)).reshape(H, W, 3))
+        with pytest.raises(ValueError):
+            dw.render_rgb8(cam, out=np.zeros((H, W, 4), dtype=np.uint8))
+        dw.close()
+
+
+def test_rows_bands_views_with_only_the_8bit_output(rtc, gpu, scenes):
+    """d_rgb = NULL, d_rgb8 given: rtc_render_rows / _bands / _views write the 8-bit rows only; both NULL is an error."""
+    import torch
+    W, H = 160, 93
+    w, cam = scenes.synthetic(25, W, H, reflective=True)
+    dw = gpu.upload(w)
+    full8 = rtc.color_scale255(dw.render(cam)).reshape(H, W, 3)
+    q = torch.full((H, W, 3), 9, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    dw.render_rows(cam, 0, H, None, d_ptr8=q.data_ptr())
+    gpu.synchronize()
+    assert np.array_equal(q.cpu().numpy(), full8)
+    per = rtc.group_packed_rows(H, 2)
+    t = torch.full((2, 1, per, W, 3), 9, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    for r in range(2):
+        dw.render_bands(cam, r, 2, None, d_ptr8=t[r].data_ptr())
+    gpu.synchronize()
+    assert np.array_equal(rtc.group_undeal_host(t.cpu().numpy(), 2, 1, H)[0], full8)
+    v = torch.full((2 * 96, W, 3), 9, dtype=torch.uint8, device="cuda:0")
+    torch.cuda.synchronize()
+    dw.render_views([cam, cam], 0, 1, None, 96, d_ptr8=v.data_ptr())
+    gpu.synchronize()
+    vh = v.cpu().numpy()
+    assert np.array_equal(vh[:H], full8) and np.array_equal(vh[96:96 + H], full8)
+    with pytest.raises(rtc.RtcError):
+        dw.render_rows(cam, 0, H, None)
+    dw.close()
+
+
+def test_group_host_rgb8(rtc, scenes):
+    """rtc_group_render_host_rgb8: every member DMAs its 8-bit bands straight to their rows of ONE host frame
+    (members rehearsed on one device with peer copies, as in test_gpu_group.py)."""
+    W, H = 200, 117
+    w, cam = scenes.synthetic(30, W, H)
+    c = rtc.Context(0)
+    ref = c.upload(w).render(cam)
+    c.close()
+    want8 = rtc.color_scale255(ref).reshape(H, W, 3)
+    for devices in ([0], [0, 0], [0, 0, 0]):
+        g = rtc.Group(devices=devices, exchange=rtc.EXCHANGE_P2P)
+        gw = g.upload(w)
+        for out in (np.zeros((H, W, 3), dtype=np.uint8), rtc.host_canvas_rgb8(H, W)):
+            got, st = gw.render_host_rgb8(cam, out, with_stats=True)
+            assert np.array_equal(got, want8), len(devices)
+            assert st["rays_primary"] == W * H
+        f64 = np.zeros((H, W, 3))
+        assert np.array_equal(gw.render_host(cam, f64), ref)     # the f64 host canvas after the 8-bit one: buffers are separate
+        assert [x.device for x in g.contexts] == devices
+        gw.close()
+        g.close()
+
+
+def test_launch_info_and_the_lds_table_flag(rtc, gpu, scenes):
+    """rtc_context_last_launch_info names the object source; RTC_FLAG_NO_CULL | RTC_FLAG_LDS_TABLE selects the LDS-staged
+    brute force (BASELINE.json north_star's literal kernel) for any World size — same pixels, same ray counts."""
+    import torch
+    for n, want_default, want_lds in ((100, 3, 1), (700, 4, 1), (1500, 4, 2)):
+        W, H = 96, 54
+        w, cam = scenes.synthetic(n, W, H)
+        dw = gpu.upload(w)
+        a, sa = dw.render(cam, with_stats=True)
+        assert gpu.last_launch_info()["source"] == want_default
+        b, sb = dw.render(cam, flags=rtc.FLAG_NO_CULL | rtc.FLAG_LDS_TABLE, with_stats=True)
+        info = gpu.last_launch_info()
+        assert info["source"] == want_lds and info["dynamic_lds_bytes"] > 0 and not info["binned_primary_pass"], info
+        c, sc = dw.render(cam, flags=rtc.FLAG_NO_CULL, with_stats=True)
+        assert gpu.last_launch_info()["source"] in (0, 1, 2)
+        assert np.array_equal(a, b) and np.array_equal(a, c) and sa == sb == sc, n
+        dw.close()
+
+
+def test_forced_one_level_cull_beyond_256_objects(rtc, scenes):
+    """RTC_SRC=3 (the one-level cull forced for an A/B run) on a World of 700 objects with light lists: the listed shadow
+    branch keeps a 256-bit 'done' set and must not be taken (objects j and j + 256 would share a bit); canvases equal the
+    default context's (two-level cull) and the walk's (RTC_LIGHT_LISTS=0), bit for bit."""
+    W, H = 240, 135
+    w, cam = scenes.synthetic(700, W, H)
+    c0 = rtc.Context(0)
+    want, st0 = c0.upload(w).render(cam, with_stats=True)
+    c0.close()
+    for env in (dict(RTC_SRC=3), dict(RTC_SRC=3, RTC_LIGHT_LISTS=0), dict(RTC_SRC=3, RTC_BINNING=0)):
+        c = _ctx_env(rtc, **env)
+        got, st = c.upload(w).render(cam, with_stats=True)
+        assert c.last_launch_info()["source"] == 3
+        assert np.array_equal(got, want) and st == st0, env
+        c.close()

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol(rtc):
     L = rtc.lib()
     for name in declared:
         assert getattr(L, name) is not None
-    assert L.rtc_abi_version() == 2
+    assert L.rtc_abi_version() == 3
     assert L.rtc_strerror(1) == b"Matrix is not invertable"  # transform.rs:177 panic text
 
 
@@ -364,3 +364,30 @@ def test_loader_and_writers_under_address_and_ub_sanitizers(tmp_path):
     r = subprocess.run([str(exe), str(ROOT / "raytracer-challenge_amd" / "data" / "reflect_refract.yml")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
     assert "no crash" in r.stdout
+
+
+def test_bench_bare_gpus_n_starts_its_ranks_as_children():
+    """`python bench.py --gpus 2` outside torchrun must start the ranks itself (torch.distributed.run as a CHILD process,
+    before any HIP call in the parent) and hand their exit status on. Here there is no GPU: both ranks must say so and the
+    parent must return non-zero — not hang, not re-exec, not ask for torchrun."""
+    import subprocess
+    import sys
+    root = Path(__file__).resolve().parents[1]
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0", "--lean"],
+                       capture_output=True, text=True, timeout=300, cwd=str(root))
+    assert r.returncode != 0
+    assert "needs `python -m torch.distributed.run" not in (r.stdout + r.stderr)
+    assert "no HIP device is visible" in (r.stdout + r.stderr)
+
+
+def test_ppm_from_the_quantised_frame_equals_ppm_from_the_canvas(rtc):
+    """rtc_canvas_format_ppm_rgb8(Color::scale'd bytes) == rtc_canvas_format_ppm(f64 canvas) (canvas.rs:98-104 quantises
+    with Color::scale): edge values included (negative, > 1, NaN, inf, exactly on a step)."""
+    rng = np.random.default_rng(5)
+    c = rng.uniform(-0.2, 1.3, (37, 50, 3))
+    c[0, 0] = (np.nan, np.inf, -np.inf)
+    c[1, 1] = (1.0, 0.0, 254.0 / 255.0)
+    c[2, 2] = (255.999 / 255.0, 0.999999 / 255.0, 128.0 / 255.0)
+    q = rtc.color_scale255(c).reshape(c.shape)
+    assert rtc.format_ppm_rgb8(q) == rtc.format_ppm(c)
+    assert rtc.format_ppm_rgb8(q).startswith(b"P3\n50 37\n255\n")
