@@ -270,7 +270,8 @@ def run_single(args, rtc, np, torch, dev, dev_index, world, cam, cam_arr, wkey, 
     ctx = rtc.Context(dev_index, stream=torch.cuda.current_stream(dev).cuda_stream)
     dworld = ctx.upload(world)
     R = args.canvases
-    ring = [torch.zeros((V * H, W, 3), dtype=torch.float64, device=dev) for _ in range(R)]   # Camera::render_async returns a NEW Canvas per call
+    HP = -(-H // 8) * 8     # rows one view occupies in a multi-view launch (whole 8-row bands)
+    ring = [torch.zeros(((V * HP) if V > 1 else H, W, 3), dtype=torch.float64, device=dev) for _ in range(R)]   # Camera::render_async returns a NEW Canvas per call
     ptrs = [t.data_ptr() for t in ring]
     torch.cuda.synchronize(dev)
     state = {"i": 0}
@@ -281,7 +282,7 @@ def run_single(args, rtc, np, torch, dev, dev_index, world, cam, cam_arr, wkey, 
         if V == 1:
             dworld.render_rows(cam, 0, H, ptrs[i % R], rtc.MODE_RENDER_ASYNC)
         else:
-            dworld.render_views(cam_arr[V], 0, 1, ptrs[i % R], H, rtc.MODE_RENDER_ASYNC)
+            dworld.render_views(cam_arr[V], 0, 1, ptrs[i % R], HP, rtc.MODE_RENDER_ASYNC)
     sync = ctx.synchronize
 
     def solo_leg(n):
@@ -388,11 +389,11 @@ def run_single(args, rtc, np, torch, dev, dev_index, world, cam, cam_arr, wkey, 
                                      "note": "the headline's launches in order on ONE stream (rtc_context_set_pipeline(1), round 2's `single_view`)"}
         # (2) a batch: VB distinct cameras per launch (rtc_render_views), in order, binning on the side stream
         if VB > 1 and V == 1:
-            big = torch.zeros((VB * H, W, 3), dtype=torch.float64, device=dev)
+            big = torch.zeros((VB * HP, W, 3), dtype=torch.float64, device=dev)
             torch.cuda.synchronize(dev)
 
             def launch_b():
-                dworld.render_views(cam_arr[VB], 0, 1, big.data_ptr(), H, rtc.MODE_RENDER_ASYNC)
+                dworld.render_views(cam_arr[VB], 0, 1, big.data_ptr(), HP, rtc.MODE_RENDER_ASYNC)
             nb = max(2, n2 // VB)
             dt, s2 = loop(launch_b, nb)
             ctx.set_timing(1)

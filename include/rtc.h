@@ -250,6 +250,23 @@ rtc_status  rtc_scene_load_yaml(const char *text, rtc_shape **shapes_out, uint32
 rtc_status  rtc_scene_load_yaml_file(const char *path, rtc_shape **shapes_out, uint32_t *n_out,
                                      rtc_light *light_out, rtc_camera *camera_out,
                                      char *errbuf, size_t errbuf_len);
+/* Scene loader for the TABLE-LITERAL subset of the reference's Lua front-end (ch1/src/lua.rs:57-79,109-330; scenes like
+ * ch1/jamis.lua:1-56): global assignments of table constructors, constant arithmetic (math.pi), and
+ * `Render(world, camera, "file")` calls. The tables are turned into World and Camera by lua.rs's own rules —
+ * transform_from_table's fixed order rotate_x, rotate_y, rotate_z, scale, position; materials from Material::default()
+ * with the keys ambient, diffuse, specular, shininess, reflectiveness, transparency, refractive_index, color, pattern
+ * (anything else is an error) and the shape-level color / pattern override; patterns "checks" / "stripes" / "grid";
+ * lights[1] only; camera screenwidth / screenheight / samples as Lua integers. `render_index` selects the k-th Render
+ * call of the script (0 = the first; a script without any falls back to its globals `world` and `camera`);
+ * *renders_out (may be NULL) = how many the script makes; `outfile` (may be NULL) receives that call's file name.
+ * Anything that needs an interpreter — functions, loops, require, calls other than Render — is RTC_ERR_PARSE with a
+ * message saying so (ex2.lua, functions.lua). PARITY UNPINNED: the reference has no test of its Lua path. [host] */
+rtc_status  rtc_scene_load_lua(const char *text, uint32_t render_index, rtc_shape **shapes_out, uint32_t *n_out,
+                               rtc_light *light_out, rtc_camera *camera_out, char *outfile, size_t outfile_len,
+                               uint32_t *renders_out, char *errbuf, size_t errbuf_len);
+rtc_status  rtc_scene_load_lua_file(const char *path, uint32_t render_index, rtc_shape **shapes_out, uint32_t *n_out,
+                                    rtc_light *light_out, rtc_camera *camera_out, char *outfile, size_t outfile_len,
+                                    uint32_t *renders_out, char *errbuf, size_t errbuf_len);
 void        rtc_free(void *p);
 
 /* Canvas::write_to_file_simple: ASCII PPM P3 (canvas.rs:86-109) with Color::scale's

@@ -248,6 +248,28 @@ def load_yaml(text: str | None = None, path: str | None = None):
     return w, cam
 
 
+def load_lua(text: str | None = None, path: str | None = None, render_index: int = 0):
+    """Table-literal subset of the reference's Lua scenes (rtc_scene_load_lua) -> (World, RtcCamera, outfile, n_render_calls)."""
+    shapes = C.POINTER(RtcShape)()
+    n, renders = C.c_uint32(0), C.c_uint32(0)
+    lgt, cam = RtcLight(), RtcCamera()
+    err, outfile = C.create_string_buffer(512), C.create_string_buffer(512)
+    if path is not None:
+        st = lib().rtc_scene_load_lua_file(str(path).encode(), render_index, C.byref(shapes), C.byref(n), C.byref(lgt), C.byref(cam), outfile, 512,
+                                           C.byref(renders), err, 512)
+    else:
+        st = lib().rtc_scene_load_lua(text.encode(), render_index, C.byref(shapes), C.byref(n), C.byref(lgt), C.byref(cam), outfile, 512,
+                                      C.byref(renders), err, 512)
+    _check(st, "rtc_scene_load_lua", err.value.decode(errors="replace"))
+    w = World(lgt)
+    for i in range(n.value):
+        s = RtcShape()
+        C.memmove(C.byref(s), C.byref(shapes[i]), C.sizeof(RtcShape))
+        w.shapes.append(s)
+    lib().rtc_free(shapes)
+    return w, cam, outfile.value.decode(errors="replace"), renders.value
+
+
 def format_ppm(rgb: np.ndarray) -> bytes:
     """Canvas::write_to_file_simple (canvas.rs:86-109) into memory."""
     a = np.ascontiguousarray(rgb, dtype=np.float64)
@@ -686,7 +708,7 @@ def group_undeal_host(staging: np.ndarray, nranks: int, nframes: int, vsize: int
 
 
 __all__ = ["lib", "RtcError", "Matrix", "material", "sphere", "plane", "cube", "light", "World", "camera", "ray_for_pixel",
-           "load_yaml", "format_ppm", "write_ppm", "color_scale255", "Context", "DeviceWorld", "MODE_RENDER", "MODE_RENDER_ASYNC", "FLAG_NONE", "FLAG_NO_CULL", "FLAG_AA_RESAMPLE", "Group", "GroupWorld", "group_unique_id",
+           "load_yaml", "load_lua", "format_ppm", "write_ppm", "color_scale255", "Context", "DeviceWorld", "MODE_RENDER", "MODE_RENDER_ASYNC", "FLAG_NONE", "FLAG_NO_CULL", "FLAG_AA_RESAMPLE", "Group", "GroupWorld", "group_unique_id",
            "host_register", "host_unregister", "host_canvas", "host_canvas_rgb8", "format_ppm_rgb8", "write_ppm_rgb8",
            "group_packed_rows", "group_bands_owned", "group_row_owner", "group_packed_row_to_image", "group_undeal_host", "EXCHANGE_RCCL", "EXCHANGE_P2P", "GATHER_NONE", "GATHER_F64", "GATHER_U8",
            "SPHERE", "PLANE", "CUBE", "RtcCamera", "RtcHit", "RtcLight", "RtcMaterial", "RtcShape", "RtcStats"]

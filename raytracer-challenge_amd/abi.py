@@ -90,6 +90,10 @@ PROTOTYPES = {
                                         C.POINTER(RtcCamera), C.c_char_p, C.c_size_t]),
     "rtc_scene_load_yaml_file": (C.c_int32, [C.c_char_p, C.POINTER(C.POINTER(RtcShape)), C.POINTER(U32), C.POINTER(RtcLight),
                                              C.POINTER(RtcCamera), C.c_char_p, C.c_size_t]),
+    "rtc_scene_load_lua": (C.c_int32, [C.c_char_p, U32, C.POINTER(C.POINTER(RtcShape)), C.POINTER(U32), C.POINTER(RtcLight),
+                                       C.POINTER(RtcCamera), C.c_char_p, C.c_size_t, C.POINTER(U32), C.c_char_p, C.c_size_t]),
+    "rtc_scene_load_lua_file": (C.c_int32, [C.c_char_p, U32, C.POINTER(C.POINTER(RtcShape)), C.POINTER(U32), C.POINTER(RtcLight),
+                                            C.POINTER(RtcCamera), C.c_char_p, C.c_size_t, C.POINTER(U32), C.c_char_p, C.c_size_t]),
     "rtc_free": (None, [VP]),
     "rtc_canvas_write_ppm": (C.c_int32, [C.c_char_p, PD, U32, U32]),
     "rtc_canvas_format_ppm": (C.c_size_t, [PD, U32, U32, C.c_char_p, C.c_size_t]),

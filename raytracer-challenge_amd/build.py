@@ -17,7 +17,7 @@ ROOT = PKG.parent
 CSRC = PKG / "csrc"
 LIB = PKG / "librtc.so"
 
-SOURCES = ["host_math.cpp", "host_ppm.cpp", "host_yaml.cpp", "rtc_api.cpp", "rtc_group.cpp", "rtc_kernels.hip"]
+SOURCES = ["host_math.cpp", "host_ppm.cpp", "host_yaml.cpp", "host_lua.cpp", "rtc_api.cpp", "rtc_group.cpp", "rtc_kernels.hip"]
 COMMON = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", f"-I{ROOT / 'include'}", f"-I{CSRC}"]
 COMMON += os.environ.get("RTC_CXXFLAGS", "").split()  # experiments, e.g. -DRTC_WAVES_PER_SIMD=4
 # Kernel file only: MachineLICM hoists the VGPR materialisation of every f64 literal (pow's ~25

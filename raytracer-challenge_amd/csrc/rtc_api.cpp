@@ -217,6 +217,9 @@ void fill_world(RenderParams &P, const rtc_world *w) {
     P.orig_s = w->d_orig_s;
     P.gbound = w->d_gbound;
     P.idtab = w->d_idtab;
+    P.pre = w->d_pre;
+    P.pre_s = w->d_pre_s;
+    P.pre_limit = w->pre_limit;
     P.light_cnt = w->d_light_cnt;
     P.light_list = w->d_light_list;
     P.light_reach = w->light_reach;
@@ -473,9 +476,31 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
         gbound[g] = gb;
     }
 
+    // per-lane prefilter records (DevPre, rtc_device.h): pre-inflated for every ray origin within 64x the extent of the bounded
+    // objects around the world origin (secondary rays start on surfaces; a floor hit near the horizon can be farther: such a pass
+    // takes the general test). The inflation is relative ~k*D^2 (1e-13 * 1e4..1e8 for ordinary scenes): generous limits cost nothing.
+    double extent = 1.;
+    for (uint32_t i = 0; i < n; ++i)
+        if (std::isfinite(bound[i].r)) extent = std::fmax(extent, std::fabs(bound[i].cx) + std::fabs(bound[i].cy) + std::fabs(bound[i].cz) + bound[i].r);
+    const double pre_limit = 64. * extent;
+    auto pre_of = [&](const DevBound &b) {
+        DevPre q{b.cx, b.cy, b.cz, INFINITY};
+        if (std::isfinite(b.r) && std::isfinite(pre_limit)) {
+            const double Dw = (std::fabs(b.cx) + std::fabs(b.cy) + std::fabs(b.cz) + pre_limit) * (1. + 1e-12);
+            const double R = ((b.r + b.r * (b.k * Dw * (b.cn + Dw))) * 1.000001 + 1e-12) * (1. + 1e-12);
+            const double R2 = R * R * (1. + 1e-12);
+            if (std::isfinite(R2)) q.R2 = R2;
+        }
+        return q;
+    };
+    std::vector<DevPre> pre(na), pre_s(na);
+    for (uint32_t i = 0; i < na; ++i) pre[i] = pre_s[i] = DevPre{0., 0., 0., INFINITY};
+    for (uint32_t i = 0; i < n; ++i) { pre[i] = pre_of(bound[i]); pre_s[i] = pre_of(bound_s[i]); }
+
     rtc_world *w = new (std::nothrow) rtc_world;
     if (!w) return RTC_ERR_NOMEM;
     w->ctx = ctx;
+    w->pre_limit = std::isfinite(pre_limit) ? pre_limit : 0.;
     w->ngroups = ngroups;
     w->device = ctx->device;
     w->n = n;
@@ -492,7 +517,9 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
               hipMalloc(&w->d_bound_s, sizeof(DevBound) * na) == hipSuccess &&
               hipMalloc(&w->d_orig_s, sizeof(uint32_t) * na) == hipSuccess &&
               hipMalloc(&w->d_gbound, sizeof(DevBound) * gbound.size()) == hipSuccess &&
-              hipMalloc(&w->d_idtab, sizeof(DevIdEntry) * na) == hipSuccess;
+              hipMalloc(&w->d_idtab, sizeof(DevIdEntry) * na) == hipSuccess &&
+              hipMalloc(&w->d_pre, sizeof(DevPre) * na) == hipSuccess &&
+              hipMalloc(&w->d_pre_s, sizeof(DevPre) * na) == hipSuccess;
     for (uint32_t i = 0; i < n; ++i)
         if (!std::isfinite(bound_s[i].r)) w->n_unb = i + 1u; // unbounded objects sort first (key 0)
     ok = ok && hipMemcpy(w->d_isect, isect.data(), sizeof(DevIsect) * na, hipMemcpyHostToDevice) == hipSuccess &&
@@ -505,6 +532,8 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
          hipMemcpy(w->d_orig_s, orig_s.data(), sizeof(uint32_t) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_gbound, gbound.data(), sizeof(DevBound) * gbound.size(), hipMemcpyHostToDevice) == hipSuccess &&
          hipMemcpy(w->d_idtab, idtab.data(), sizeof(DevIdEntry) * na, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(w->d_pre, pre.data(), sizeof(DevPre) * na, hipMemcpyHostToDevice) == hipSuccess &&
+         hipMemcpy(w->d_pre_s, pre_s.data(), sizeof(DevPre) * na, hipMemcpyHostToDevice) == hipSuccess &&
          hipMemset(w->d_prim, 0, sizeof(DevPrim) * na) == hipSuccess;
     // light-space shadow lists: every shadow segment ends at the light, so the objects a segment can meet
     // are listed per direction cell of a cube map around the light, once per World. Reach = twice the far side of the
@@ -556,6 +585,8 @@ void rtc_world_destroy(rtc_world *w) {
     if (w->d_orig_s) (void)hipFree(w->d_orig_s);
     if (w->d_gbound) (void)hipFree(w->d_gbound);
     if (w->d_idtab) (void)hipFree(w->d_idtab);
+    if (w->d_pre) (void)hipFree(w->d_pre);
+    if (w->d_pre_s) (void)hipFree(w->d_pre_s);
     for (rtc_world::BinSet &b : w->bin) {
         if (b.tile_cnt) (void)hipFree(b.tile_cnt);
         if (b.tile_list) (void)hipFree(b.tile_list);

@@ -52,6 +52,15 @@ struct DevBound {
     double k;             // 0.75e-14 * ||A||_F^2 (A = 3x3 of the stored inverse): rounding inflation
     double cn;            // |centre|: see the note on rounding below
 };
+// The per-lane prefilter's own record (ray_touches_pre, rtc_kernels.hip): centre and SQUARED radius of the bounding sphere with
+// the rounding inflation of the note below already applied for every ray origin within |o|_1 <= pre_limit (RenderParams) —
+// D <= |C - o|_1 <= |C|_1 + pre_limit, so R = r * (1 + k * Dw * (cn + Dw)) * 1.000001 + 1e-12 with Dw = |C|_1 + pre_limit is
+// an upper bound of what ray_touches computes per lane. 32 bytes instead of 48, and 15 instead of 26 instructions per test;
+// a pass with an origin beyond the limit takes the general test. R2 = +inf: unbounded, never culled.
+struct DevPre {
+    double cx, cy, cz, R2;
+};
+
 // Binned primary pass. Per render and view one kernel (k_bin_tiles) puts every object on the list of each 8x8-pixel tile
 // whose primary-ray cone its bounding sphere can touch — the SAME conservative predicate the wave-level cull applies
 // (bundle_touches), against a cone built from the tile's corner rays (cell_cone). The render kernel's primary pass then runs
@@ -146,6 +155,9 @@ struct RenderParams {
     const uint32_t *orig_s;    // [n] sorted position -> insertion index (World.shapes order)
     const DevBound *gbound;    // [ngroups] sphere around each group of 64 sorted objects
     const DevIdEntry *idtab;   // [n] shapes in stable order of world_id (compute_refractive's container key)
+    const DevPre *pre;         // [n] prefilter records, insertion order
+    const DevPre *pre_s;       // [n] ... in sorted order
+    double pre_limit;          // the records hold for ray origins with |o|_1 <= pre_limit
     // binned primary pass (nullptr: not available for this launch): per view `tiles_x * tiles_y` counters and lists of
     // RTC_TILE_LIST_CAP insertion indices, image tile (tx, ty) of view v at (v * tiles_y + ty) * tiles_x + tx
     const uint32_t *tile_cnt;

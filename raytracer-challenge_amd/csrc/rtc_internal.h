@@ -79,6 +79,8 @@ struct rtc_world {
     uint32_t *d_orig_s = nullptr;
     DevBound *d_gbound = nullptr;
     DevIdEntry *d_idtab = nullptr;
+    DevPre *d_pre = nullptr, *d_pre_s = nullptr; // per-lane prefilter records (insertion / sorted order)
+    double pre_limit = 0.;
     // binned primary pass: per-render scratch, grow-only, TWO sets — the binning of launch k+1 runs on the context's side
     // stream while launch k's render kernel still reads set k (rtc_render_* take the World as const: mutable)
     struct BinSet {

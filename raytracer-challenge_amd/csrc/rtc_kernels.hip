@@ -592,6 +592,25 @@ DEVI bool ray_touches(V3 o, V3 d, const DevBound &b) {
     return !(ww * dd - proj * proj > R2 * dd + 1e-11 * ww * dd); // NaN-safe: keep unless provably far
 }
 
+// The same question against a pre-inflated record (DevPre, rtc_device.h) — valid for origins with |o|_1 <= pre_limit, which the
+// caller checks once per pass. One inequality: with pm = max(proj, 0) the squared distance from the centre to the RAY (t >= 0)
+// is ww - pm^2 / dd, so the sphere can be touched only if ww*dd - pm^2 <= R2*dd (+ the cancellation slack); proj < 0 turns it
+// into ww <= R2 (origin inside), as the general test has it. `dd` = d.d, computed once per pass.
+DEVI bool ray_touches_pre(V3 o, V3 d, double dd, const DevPre &b) {
+#pragma clang fp contract(fast) // cull arithmetic
+    const double wx = b.cx - o.x, wy = b.cy - o.y, wz = b.cz - o.z;
+    const double ww = wx * wx + wy * wy + wz * wz;
+    const double pm = fmax(wx * d.x + wy * d.y + wz * d.z, 0.);
+    return !(ww * dd - pm * pm > (b.R2 + 1e-11 * ww) * dd); // NaN-safe: keep unless provably far; R2 = inf: never culled
+}
+// Candidates of a per-lane-filtered walk are taken RTC_PRE_BATCH at a time: their records are requested together and their
+// prefilters evaluated back to back before any exact test, so that a pass over many candidates — a secondary pass whose bundle
+// cannot be bounded visits all 101 objects of the reflective north star — is not one scalar-load round trip per object
+// (profiles/r03_exp_unbounded_walks.log: those walks, 0.27 passes per wave, were a third of C4's kernel time).
+#ifndef RTC_PRE_BATCH
+#define RTC_PRE_BATCH 2
+#endif
+
 // ---- wave-uniform object loop ------------------------------------------------------------
 // f(j, m, kind, prim) is called for objects j = 0..n-1 in insertion order (World::intersect,
 // shape.rs:679-681) and returns true while some lane of the wave still needs objects.
@@ -616,6 +635,8 @@ struct Tables {
     const uint32_t *__restrict__ orig_s;
     const DevBound *__restrict__ gbound;
     const DevIdEntry *__restrict__ idtab; // shapes in stable order of world_id (n1/n2 pass)
+    const DevPre *__restrict__ pre;       // per-lane prefilter records, insertion order / sorted order
+    const DevPre *__restrict__ pre_s;
 };
 
 struct LdsView {
@@ -665,6 +686,14 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
                           V3 fro = V3{0., 0., 0.}, V3 frd = V3{0., 0., 0.}, SK skip = SK{}, unsigned *nfilt = nullptr,
                           unsigned *ngrp = nullptr, unsigned *nobj = nullptr) {
     constexpr bool ORDERED = !__is_same(SK, NoSkip);
+    // per-lane prefilter: the pre-inflated records hold while every origin of the pass is within their limit
+    bool pre_ok = false;
+    double fdd = 0.;
+    if constexpr (LANE_FILTER) {
+#pragma clang fp contract(fast)
+        pre_ok = ballot(lane_needs && !(fabs(fro.x) + fabs(fro.y) + fabs(fro.z) <= P.pre_limit)) == 0ull;
+        fdd = frd.x * frd.x + frd.y * frd.y + frd.z * frd.z;
+    }
     if constexpr (SRC == SRC_CULL) {
         // One-level cull (small worlds): up to RTC_OBJ_SLOTS x 64 objects per round, each lane tests one object's sphere of
         // every slot against the wave's bundle (the slots' loads are in flight together: one load -> test -> ballot
@@ -685,6 +714,41 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
 #pragma unroll
             for (uint32_t sl = 0; sl < OS; ++sl) {
                 unsigned long long mask = masks[sl];
+                if constexpr (LANE_FILTER) {
+                    if (pre_ok) { // RTC_PRE_BATCH candidates at a time (see ray_touches_pre)
+                        while (mask) {
+                            uint32_t jx[RTC_PRE_BATCH];
+                            unsigned long long bx[RTC_PRE_BATCH];
+                            uint32_t cnt = 0;
+#pragma unroll
+                            for (uint32_t k = 0; k < RTC_PRE_BATCH; ++k) {
+                                jx[k] = jx[0];
+                                if (mask) {
+                                    jx[k] = base + sl * 64u + (uint32_t)__builtin_ctzll(mask);
+                                    mask &= mask - 1ull;
+                                    cnt = k + 1u;
+                                }
+                            }
+                            DevPre q[RTC_PRE_BATCH]; // all requested before the first is used: one round trip for the batch
+#pragma unroll
+                            for (uint32_t k = 0; k < RTC_PRE_BATCH; ++k) q[k] = T.pre[jx[k]];
+#pragma unroll
+                            for (uint32_t k = 0; k < RTC_PRE_BATCH; ++k) {
+                                DIAG_FILTER(nfilt);
+                                const bool t = ray_touches_pre(fro, frd, fdd, q[k]); // (evaluated by every lane: no branch around the loads)
+                                bx[k] = ballot(lane_needs & t);
+                            }
+#pragma unroll
+                            for (uint32_t k = 0; k < RTC_PRE_BATCH; ++k) {
+                                if (k >= cnt || bx[k] == 0ull) continue;
+                                const DevIsect rec = T.isect[jx[k]]; // record and kind requested together, ahead of the callback's branches
+                                const uint32_t kd = T.kind[jx[k]];
+                                if (!f((int)jx[k], rec.m, kd, (const double *)nullptr)) return;
+                            }
+                        }
+                        continue;
+                    }
+                }
                 while (mask) {
                     const uint32_t jj = base + sl * 64u + (uint32_t)__builtin_ctzll(mask);
                     mask &= mask - 1ull;
@@ -738,7 +802,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
                     DIAG_FILTER(nobj);
                     if constexpr (LANE_FILTER) {
                         DIAG_FILTER(nfilt);
-                        if (ballot(lane_needs && ray_touches(fro, frd, T.bound_s[jj])) == 0ull) continue;
+                        if (ballot(lane_needs && (pre_ok ? ray_touches_pre(fro, frd, fdd, T.pre_s[jj]) : ray_touches(fro, frd, T.bound_s[jj]))) == 0ull) continue;
                     }
                     const DevIsect *rec = T.isect_s + jj;
                     if (!f((int)T.orig_s[jj], rec->m, T.kind_s[jj], (const double *)nullptr)) return false;
@@ -985,7 +1049,8 @@ __global__ void __launch_bounds__(RTC_BLOCK_FOR(CULL_LEVEL(SRC), REFL, REFR, PRO
 k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const uint32_t *__restrict__ t_kind,
         const DevShade *__restrict__ t_shade, const DevPrim *__restrict__ t_prim, const DevBound *__restrict__ t_bound,
         const DevIsect *__restrict__ t_isect_s, const uint32_t *__restrict__ t_kind_s, const DevBound *__restrict__ t_bound_s,
-        const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound, const DevIdEntry *__restrict__ t_idtab) {
+        const uint32_t *__restrict__ t_orig_s, const DevBound *__restrict__ t_gbound, const DevIdEntry *__restrict__ t_idtab,
+        const DevPre *__restrict__ t_pre, const DevPre *__restrict__ t_pre_s) {
     constexpr uint32_t BLOCK = RTC_BLOCK_FOR(CULL_LEVEL(SRC), REFL, REFR, PROBE), TILE_W = RTC_TILE_W_FOR(CULL_LEVEL(SRC), REFL, REFR, PROBE);
     constexpr bool COMPACT = RTC_COMPACT_FOR(CULL_LEVEL(SRC), REFL, REFR, PROBE); // K3: two waves, live rays merged between bounces
     extern __shared__ double lds_raw[];
@@ -1006,6 +1071,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     T.isect = t_isect; T.kind = t_kind; T.shade = t_shade; T.prim = t_prim; T.bound = t_bound;
     T.isect_s = t_isect_s; T.kind_s = t_kind_s; T.bound_s = t_bound_s; T.orig_s = t_orig_s; T.gbound = t_gbound;
     T.idtab = t_idtab;
+    T.pre = t_pre; T.pre_s = t_pre_s;
 
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
@@ -1224,6 +1290,11 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             STAMP(2); // primary bundle built
             DIAG(0, ballot(tracing) != 0ull ? 1u : 0u);
             DIAG(1, (ballot(tracing) != 0ull && B.off) ? 1u : 0u);
+            DIAG(12, (ballot(tracing) != 0ull && !first) ? 1u : 0u); // secondary closest passes
+#ifdef RTC_STAMPS
+            const unsigned diag_c2_before = diag_c[2], diag_c5_before = diag_c[5];
+            const bool diag_secondary = !first;
+#endif
             if (!IS_CULL(SRC) && shared_origin && first) {
                 for_each_object<SRC>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
                     DIAG(2, 1u);
@@ -1233,6 +1304,9 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
 #ifndef RTC_NO_LANE_FILTER
             } else if (IS_CULL(SRC) && ((REFL && !(shared_origin && first)) || RTC_PRIMARY_LANE_FILTER(SRC))) {
                 // reflection / refraction rays: incoherent, per-lane prefilter before the exact test
+#ifdef RTC_EXP_SKIP_UNBOUNDED
+                if (!B.off)
+#endif
                 for_each_object<SRC, true>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
                     DIAG(2, 1u);
                     if (tracing) closest_world(kind, m, ro, rd, j, best, hidx, hroot);
@@ -1413,6 +1487,9 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             // ---- is_shadowed (shape.rs:712-727): any-hit with early exit ----------------------
             STAMP(4); // hit record + shadow ray
             bool sh_pending = hit, shadowed = false;
+#ifdef RTC_EXP_SKIP_SECONDARY_SHADOW
+            if (!first) sh_pending = false;
+#endif
             c_shadow += popc64(ballot(hit));
             Bundle Bs{};
             Bs.off = true;
@@ -1426,39 +1503,62 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 // (Pl.n <= 256: the "done" set below has one bit per object; a larger World only gets here with the one-level
                 // cull FORCED, RTC_SRC=3, and then takes the bundle walk)
                 if (Pl.light_cnt != nullptr && Pl.n <= 256u && ballot(hit) != 0ull && ballot(hit && !(sdist <= Pl.light_reach)) == 0ull) {
+                    static_assert(RTC_LIGHT_LIST_CAP_SMALL <= 16u, "a quarter of the wave holds one cell's list");
+                    // Round trips, not instructions, are what this path costs: the cells' counters come with ONE
+                    // per-lane load (every lane asks for its own cell's), the lists of up to four distinct cells with ONE more
+                    // (lanes 16c..16c+15 hold cell c's entries); only the listed objects' own records are fetched one by one.
                     const uint32_t cid = hit ? light_cell(vneg(sdir)) : 0u;
-                    listed = true;
-                    uint32_t ncells = 0;
-                    for (unsigned long long todo = ballot(hit); todo;) {
-                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cid, (int)__builtin_ctzll(todo));
+                    const uint32_t ccnt = hit ? Pl.light_cnt[cid] : 0u;
+                    // a cell whose list overflowed is incomplete; hit points scattered over more than four cells (shadow rays
+                    // of secondary hits) are served better by the bundle cull: fall back
+                    listed = ballot(hit && ccnt > Pl.light_cap) == 0ull && Pl.light_cap <= 16u;
+                    uint32_t cells[4] = {0u, 0u, 0u, 0u}, cnts[4] = {0u, 0u, 0u, 0u}, ncells = 0;
+                    for (unsigned long long todo = ballot(hit); todo && listed;) {
+                        const int l = (int)__builtin_ctzll(todo);
+                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cid, l);
                         todo &= ~ballot(hit && cid == c);
-                        // a cell whose list overflowed is incomplete; hit points scattered over many cells (shadow rays of
-                        // secondary hits) are served better by the bundle cull: fall back
-                        if (Pl.light_cnt[c] > Pl.light_cap || ++ncells > 4u) { listed = false; break; }
+                        if (ncells == 4u) { listed = false; break; }
+                        const uint32_t cn = (uint32_t)__builtin_amdgcn_readlane((int)ccnt, l);
+#pragma unroll
+                        for (uint32_t k = 0; k < 4u; ++k)
+                            if (k == ncells) { cells[k] = c; cnts[k] = cn; }
+                        ++ncells;
                     }
                     if (listed) {
                         for (uint32_t k = 0; k < Pl.n_unb && ballot(sh_pending) != 0ull; ++k) { // unbounded objects: never listed
                             DIAG(5, 1u);
                             if (sh_pending && occludes_world(T.kind_s[k], T.isect_s[k].m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
                         }
-                        unsigned long long done[4] = {0ull, 0ull, 0ull, 0ull}; // one bit per object (n <= 256 in this variant)
-                        for (unsigned long long todo = ballot(hit); todo && ballot(sh_pending) != 0ull;) {
-                            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cid, (int)__builtin_ctzll(todo));
-                            todo &= ~ballot(hit && cid == c);
-                            const uint32_t nl = Pl.light_cnt[c];
-                            const uint32_t *ll = Pl.light_list + (size_t)c * Pl.light_cap;
-                            for (uint32_t e = 0; e < nl; ++e) {
-                                const uint32_t j = ll[e];
-                                const unsigned long long bit = 1ull << (j & 63u);
-                                unsigned long long &word = done[(j >> 6) & 3u];
-                                if (word & bit) continue;
-                                word |= bit;
-                                DIAG_FILTER(DIAG_PTR(7));
-                                if (ballot(sh_pending && ray_touches(over, sdir, T.bound[j])) == 0ull) continue;
-                                DIAG(5, 1u);
-                                if (sh_pending && occludes_world(T.kind[j], T.isect[j].m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
-                                if (ballot(sh_pending) == 0ull) break;
-                            }
+                        const uint32_t ci = lane >> 4, ei = lane & 15u;
+                        const uint32_t myc = ci == 0u ? cells[0] : ci == 1u ? cells[1] : ci == 2u ? cells[2] : cells[3];
+                        const uint32_t mycnt = ci == 0u ? cnts[0] : ci == 1u ? cnts[1] : ci == 2u ? cnts[2] : cnts[3];
+                        const bool have = ci < ncells && ei < mycnt;
+                        const uint32_t ent = have ? Pl.light_list[(size_t)myc * Pl.light_cap + ei] : 0u;
+                        // pre-inflated prefilter records hold while every origin is within their limit (DevPre)
+                        bool pre_ok;
+                        double sdd;
+                        {
+#pragma clang fp contract(fast)
+                            pre_ok = ballot(hit && !(fabs(over.x) + fabs(over.y) + fabs(over.z) <= Pl.pre_limit)) == 0ull;
+                            sdd = sdir.x * sdir.x + sdir.y * sdir.y + sdir.z * sdir.z;
+                        }
+                        unsigned long long done[4] = {0ull, 0ull, 0ull, 0ull}; // one bit per object (n <= 256): neighbouring cells list the same objects
+                        for (unsigned long long vm = ballot(have); vm && ballot(sh_pending) != 0ull;) {
+                            const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)ent, (int)__builtin_ctzll(vm));
+                            vm &= vm - 1ull;
+                            const unsigned long long bit = 1ull << (j & 63u);
+                            unsigned long long &word = done[(j >> 6) & 3u];
+                            if (word & bit) continue;
+                            word |= bit;
+                            DIAG_FILTER(DIAG_PTR(7));
+                            bool t;
+                            if (pre_ok) { const DevPre q = T.pre[j]; t = ray_touches_pre(over, sdir, sdd, q); }
+                            else t = ray_touches(over, sdir, T.bound[j]);
+                            if (ballot(sh_pending & t) == 0ull) continue;
+                            DIAG(5, 1u);
+                            const DevIsect rec = T.isect[j]; // record and kind requested together
+                            const uint32_t kd = T.kind[j];
+                            if (sh_pending && occludes_world(kd, rec.m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
                         }
                     }
                 }
@@ -1526,6 +1626,13 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             }, over, sdir, NoSkip{}, DIAG_PTR(7), DIAG_PTR(9), DIAG_PTR(11));
 
             STAMP(6); // shadow resolved
+#ifdef RTC_STAMPS
+            if (diag_secondary) { // [13] exact tests in secondary closest passes, [14] their shadow passes, [15] exact tests in those
+                diag_c[13] += diag_c[2] - diag_c2_before;
+                diag_c[14] += ballot(hit) != 0ull ? 1u : 0u;
+                diag_c[15] += diag_c[5] - diag_c5_before;
+            }
+#endif
             // keep the material / pattern loads of the lighting stage BELOW the shadow loop: hoisted
             // above it they stay live through the loop and cost a wave per SIMD in occupancy
             asm volatile("" ::: "memory");
@@ -2176,7 +2283,7 @@ static hipError_t launch_kernel(const RenderParams &P, dim3 grid, size_t lds_byt
     }
     // e0/e1 (may be NULL) receive the dispatch's own begin/end timestamps: no marker packets on the stream
     hipExtLaunchKernelGGL((k_trace<SRC, REFL, REFR, PROBE>), grid, dim3(RTC_BLOCK_FOR(CULL_LEVEL(SRC), REFL, REFR, PROBE)), lds_bytes, stream, e0, e1, 0, P, P.isect,
-                          P.kind, P.shade, P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound, P.idtab);
+                          P.kind, P.shade, P.prim, P.bound, P.isect_s, P.kind_s, P.bound_s, P.orig_s, P.gbound, P.idtab, P.pre, P.pre_s);
     return hipGetLastError();
 }
 template <int SRC, bool REFL, bool REFR>

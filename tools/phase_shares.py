@@ -42,5 +42,7 @@ d = [out[16 + i] for i in range(16)]
 print(f"per wave: closest passes {d[0] / NW:.2f} (unbounded bundle {d[1] / NW:.2f}), exact tests/closest pass {d[2] / max(d[0], 1):.2f}; "
       f"shadow passes {d[3] / NW:.2f} (unbounded {d[4] / NW:.2f}), exact tests/shadow pass {d[5] / max(d[3], 1):.2f}; "
       f"per-lane prefilter evaluations per wave: closest {d[6] / NW:.1f}, shadow {d[7] / NW:.1f}")
+print(f"secondary (reflection / refraction) passes per wave {d[12] / NW:.2f}: exact tests per such closest pass {d[13] / max(d[12], 1):.2f}; "
+      f"their shadow passes per wave {d[14] / NW:.2f}, exact tests per such shadow pass {d[15] / max(d[14], 1):.2f}")
 print(f"two-level cull: groups expanded per closest pass {d[8] / max(d[0], 1):.2f}, per shadow pass {d[9] / max(d[3], 1):.2f}; "
       f"object-level survivors per closest pass {d[10] / max(d[0], 1):.2f}, per shadow pass {d[11] / max(d[3], 1):.2f}")
