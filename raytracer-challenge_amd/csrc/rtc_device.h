@@ -97,7 +97,7 @@ struct DevTileBundle {
 // is r * (1 + k * D * (cn + D)) with k = 0.75e-14 * ||A||_F^2 (any upper bound of D may be used).
 // For ordinary scenes the factor is 1 + 1e-9.
 
-enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PIXELS = 4, CNT_RESAMPLE = 5, CNT_STAMP0 = 8, CNT_DIAG0 = 16, CNT_N = 32 };
+enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PIXELS = 4, CNT_RESAMPLE = 5, CNT_STAMP0 = 8, CNT_DIAG0 = 16, CNT_STAMP2 = 32 /* the same phases, secondary passes only */, CNT_N = 40 };
 // Ray counters are kept in CNT_SLOTS replicas (one 64-byte line each); a wave adds to the replica
 // picked by its workgroup id, so no single word sees more than 1/CNT_SLOTS of the atomics. The host
 // sums the replicas (rtc_stats_read).

@@ -134,7 +134,10 @@ struct V3 {
 #define DIAG(i, v) do { diag_c[i] += (v); } while (0)
 #define DIAG_FILTER(p) do { if (p) *(p) += 1u; } while (0)
 #define DIAG_PTR(i) (&diag_c[i])
-#define STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); stamp_t[i] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+// STAMP(i): the time since the previous stamp (whichever it was) is added to phase i — summed over all passes of the wave in
+// stamp_t[i], and over its secondary passes only in stamp_t[8 + i].
+#define STAMP(i) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); const unsigned long long now_ = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+                      stamp_t[i] += now_ - stamp_last; if (stamp_secondary) stamp_t[8 + (i)] += now_ - stamp_last; stamp_last = now_; } while (0)
 #else
 #define STAMP(i) do { } while (0)
 #define DIAG(i, v) do { } while (0)
@@ -1114,7 +1117,9 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
 
     uint32_t c_primary = 0, c_shadow = 0, c_reflect = 0, c_refract = 0; // wave-uniform
 #ifdef RTC_STAMPS
-    unsigned long long stamp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
+    bool stamp_secondary = false;
     // per wave: [0] closest passes, [1] closest passes with an unbounded bundle, [2] exact tests in
     // closest passes, [3] shadow passes, [4] shadow passes unbounded, [5] exact tests in shadow passes
     // [8] groups expanded in closest passes, [9] in shadow passes, [10] object-level cull survivors (closest), [11] (shadow)
@@ -1263,6 +1268,9 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 pass_again = false;
             }
 
+#ifdef RTC_STAMPS
+            stamp_secondary = !first; // [1] of a secondary pass = the previous pass's lighting + frame push
+#endif
             STAMP(1); // ray generated
             // ---- World::intersect + get_hit (shape.rs:677-683, 220-232), streaming form ----
             double best = __builtin_inf();
@@ -1304,7 +1312,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
 #ifndef RTC_NO_LANE_FILTER
             } else if (IS_CULL(SRC) && ((REFL && !(shared_origin && first)) || RTC_PRIMARY_LANE_FILTER(SRC))) {
                 // reflection / refraction rays: incoherent, per-lane prefilter before the exact test
-#ifdef RTC_EXP_SKIP_UNBOUNDED
+#ifdef RTC_EXP_SKIP_UNBOUNDED // (elimination build, profiles/r03_exp_unbounded_walks.log: wrong image, never shipped)
                 if (!B.off)
 #endif
                 for_each_object<SRC, true>(P, T, L, tracing, B, [&](int j, auto m, uint32_t kind, auto pr) {
@@ -1370,6 +1378,12 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 }, ro, rd, NoSkip{}, nullptr, DIAG_PTR(8), DIAG_PTR(10));
             }
             const bool hit = tracing && hidx >= 0;
+#ifdef RTC_STAMPS
+            if (stamp_secondary && B.off) { // [8] (unused otherwise): closest-hit walks of secondary passes WITHOUT a bounded bundle (also part of [3])
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                stamp_t[8] += __builtin_amdgcn_s_memtime() - stamp_last;
+            }
+#endif
             STAMP(3); // closest hit found
             const auto &Ph = KP(P_arg); // shading view: light
             const V3 lightp = mk(Ph.light_pos[0], Ph.light_pos[1], Ph.light_pos[2]);
@@ -1487,7 +1501,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             // ---- is_shadowed (shape.rs:712-727): any-hit with early exit ----------------------
             STAMP(4); // hit record + shadow ray
             bool sh_pending = hit, shadowed = false;
-#ifdef RTC_EXP_SKIP_SECONDARY_SHADOW
+#ifdef RTC_EXP_SKIP_SECONDARY_SHADOW // (elimination build, as above)
             if (!first) sh_pending = false;
 #endif
             c_shadow += popc64(ballot(hit));
@@ -1961,7 +1975,8 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             if (c_refract) atomicAdd(slot + CNT_REFRACT, (unsigned long long)c_refract);
             if (c_resample) atomicAdd(slot + CNT_RESAMPLE, (unsigned long long)c_resample);
 #ifdef RTC_STAMPS
-            for (int i = 0; i < 7; ++i) atomicAdd(slot + CNT_STAMP0 + i, stamp_t[i + 1] - stamp_t[i]);
+            for (int i = 0; i < 8; ++i) atomicAdd(slot + CNT_STAMP0 + i, stamp_t[i]);
+            for (int i = 0; i < 8; ++i) atomicAdd(slot + CNT_STAMP2 + i, stamp_t[8 + i]);
             for (int i = 0; i < 16; ++i) atomicAdd(slot + CNT_DIAG0 + i, (unsigned long long)diag_c[i]);
 #endif
         }

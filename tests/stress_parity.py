@@ -70,12 +70,44 @@ def far_world(seed):
     return w, cam
 
 
+def mirror_world(seed):
+    """One-level worlds (<= 256 objects) of small MIRRORS: reflection rays off a sphere of a few pixels fan out over a
+    hemisphere, no cone holds them, and the pass takes the per-lane walk over groups of 8 (walk_per_lane, round 3) with its
+    distance limit; now and then glass (refraction rays likewise), cubes, flattened ellipsoids, a mirror floor, far offsets."""
+    rng = np.random.default_rng(seed)
+    u = lambda a, b: float(rng.uniform(a, b))
+    off = [0.0, 0.0, 0.0]
+    if rng.random() < 0.2:
+        mag = 10.0 ** u(1, 5)
+        off = [mag * u(-1, 1), mag * u(-1, 1) * 0.2, mag * u(-1, 1)]
+    P = lambda x, y, z: (off[0] + x, off[1] + y, off[2] + z)
+    w = rtc.World(rtc.light(P(u(-8, 8), u(3, 12), u(-10, 0))))
+    n = int(rng.integers(3, 250))
+    for i in range(n):
+        r = u(0.03, 0.25) if rng.random() < 0.8 else u(0.4, 2.0)
+        flat = u(0.05, 1.0) if rng.random() < 0.2 else 1.0
+        t = rtc.Matrix.identity().scaling(r, r * flat, r).rotation_x(u(0, 3)).translation(*P(u(-6, 6), u(0, 4), u(-3, 14)))
+        glass = rng.random() < 0.15
+        m = rtc.material(color=(u(0, 1), u(0, 1), u(0, 1)), ambient=u(0, 0.3), diffuse=u(0.2, 0.9), specular=u(0, 0.9), shininess=u(5, 300),
+                         reflective=(u(0.05, 1.0) if rng.random() < 0.8 else 0.0), transparency=(u(0.2, 1.0) if glass else 0.0),
+                         refractive_index=(u(1.0, 2.0) if glass else 1.0))
+        try:
+            w.add_shape((rtc.cube if rng.random() < 0.15 else rtc.sphere)(t, m))
+        except rtc.RtcError:
+            pass
+    if rng.random() < 0.7:
+        w.add_shape(rtc.plane(rtc.Matrix.identity().translation(*P(0, u(-0.5, 0), 0)),
+                              rtc.material(specular=0.0, reflective=u(0, 0.6), pattern=("checker", (0.3,) * 3, (0.7,) * 3, None))))
+    cam = rtc.camera(64, 40, u(0.5, 1.4), rtc.Matrix.make_view_transform(P(u(-3, 3), u(0.5, 5), u(-10, -4)), P(u(-1, 1), u(0, 2), u(2, 8)), (0, 1, 0)))
+    return w, cam
+
+
 ctx = rtc.Context(0)
 bad = 0
 t0 = time.time()
 for k in range(n_worlds):
     seed = seed0 + k
-    w, cam = far_world(seed) if k % 4 == 3 else (big_world(seed) if k % 3 == 2 else adversarial_scene(rtc, seed))
+    w, cam = mirror_world(seed) if k % 5 == 4 else (far_world(seed) if k % 4 == 3 else (big_world(seed) if k % 3 == 2 else adversarial_scene(rtc, seed)))
     dw = ctx.upload(w)
     got, st = dw.render(cam, rtc.MODE_RENDER_ASYNC, with_stats=True)
     brute, sb = dw.render(cam, rtc.MODE_RENDER_ASYNC, flags=1, with_stats=True)

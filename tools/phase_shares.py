@@ -29,15 +29,17 @@ ctx.reset_stats()
 dw.render_rows(cam, y0, y1, buf.data_ptr())
 ctx.synchronize()
 NW = 30 * ((y1 - y0 + 7) // 8) * 8  # waves launched: 8x8-pixel tiles, 32x8 blocks
-out = (C.c_ulonglong * 32)()
+out = (C.c_ulonglong * 40)()
 rtc.lib().rtc_debug_counters.argtypes = [C.c_void_p, C.POINTER(C.c_ulonglong), C.c_uint32]
-rtc.lib().rtc_debug_counters(ctx._h, out, 32)
-names = ["ray generation", "primary bundle", "primary cull + closest hit", "hit record + shadow ray", "shadow bundle",
-         "shadow cull + any-hit", "lighting + store"]
-tot = sum(out[8 + i] for i in range(7))
-print(f"objects {len(w)}  kernel_ms(stamped) {ctx.last_kernel_ms():.3f}  waves {out[0] // 64 if out[0] else 0}")
+rtc.lib().rtc_debug_counters(ctx._h, out, 40)
+# STAMP(i): time since the previous stamp, summed over the wave's passes ([8 + i]); secondary passes only ([32 + i])
+names = ["(kernel entry -> first stamp)", "pass top: ray generation / previous pass's lighting + frame push", "bundle", "closest-hit walk",
+         "hit record + n1/n2 + shadow ray", "shadow set-up (+ listed shadow walk)", "shadow walk (bundle / lists of two-level worlds)", "final lighting + tile store"]
+tot = sum(out[8 + i] for i in range(8))
+print(f"objects {len(w)}  kernel_ms(stamped) {ctx.last_kernel_ms():.3f}  waves {NW}")
 for i, nm in enumerate(names):
-    print(f"  {nm:28s} {out[8 + i] / max(tot, 1) * 100:5.1f} %   {out[8 + i] / NW:9.0f} ticks/wave")
+    print(f"  {nm:72s} {out[8 + i] / max(tot, 1) * 100:5.1f} %   {out[8 + i] / NW:9.0f} ticks/wave   of which secondary passes {out[32 + i] / NW:9.0f}")
+print(f"  closest-hit walks of secondary passes whose bundle could not be bounded: {out[32] / NW:9.0f} ticks/wave (part of the closest-hit walk row)")
 d = [out[16 + i] for i in range(16)]
 print(f"per wave: closest passes {d[0] / NW:.2f} (unbounded bundle {d[1] / NW:.2f}), exact tests/closest pass {d[2] / max(d[0], 1):.2f}; "
       f"shadow passes {d[3] / NW:.2f} (unbounded {d[4] / NW:.2f}), exact tests/shadow pass {d[5] / max(d[3], 1):.2f}; "
