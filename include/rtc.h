@@ -503,7 +503,9 @@ rtc_status  rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *ray
 
 /* Device arithmetic probe: applies op (0 sqrt, 1 a/b, 2 pow(a,b), 3 floor, 4 fmod(a,2))
  * element-wise on the GPU; used by the tests to prove f64 sqrt and division are correctly
- * rounded on gfx950 (they must be bit-identical to the host's). */
+ * rounded on gfx950 (they must be bit-identical to the host's). op 5 / 6: Vector::normalize (vec.rs:65-76) of
+ * every consecutive triple of `a` (n a multiple of 3) — 6 with three IEEE divisions, 5 with the shared-divisor form
+ * of the division expansion (rtc_kernels.hip vnormalize_shared; an experiment, must equal 6 bit for bit). */
 rtc_status  rtc_device_arith(rtc_context *ctx, uint32_t op, const double *a, const double *b,
                              uint32_t n, double *out);
 

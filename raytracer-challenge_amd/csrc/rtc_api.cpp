@@ -1070,7 +1070,7 @@ rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays
 }
 
 rtc_status rtc_device_arith(rtc_context *ctx, uint32_t op, const double *a, const double *b, uint32_t n, double *out) {
-    if (!ctx || !a || !out || op > 4 || (op == 1 && !b) || (op == 2 && !b)) return RTC_ERR_ARG;
+    if (!ctx || !a || !out || op > 6 || (op == 1 && !b) || (op == 2 && !b)) return RTC_ERR_ARG;
     if (n == 0) return RTC_OK;
     HIP_TRY(hipSetDevice(ctx->device));
     double *da = nullptr, *db = nullptr, *dout = nullptr;

@@ -154,9 +154,45 @@ DEVI V3 vneg(V3 a) { return mk(-a.x, -a.y, -a.z); }
 // Vector::dot vec.rs:78-82: (x*x' + y*y') + z*z'
 DEVI double vdot(V3 a, V3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
 // Vector::normalize vec.rs:65-76: magnitude, then three divisions
-DEVI V3 vnormalize(V3 a) {
+DEVI V3 vnormalize_plain(V3 a) {
     const double mag = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
     return mk(a.x / mag, a.y / mag, a.z / mag);
+}
+// The three IEEE divisions share their divisor. hipcc expands x / y (f64) into v_div_scale x2, v_rcp, four v_fma refining
+// 1/y, v_mul, v_fma, v_div_fmas, v_div_fixup (11 instructions); everything up to the refined reciprocal depends on y alone
+// as long as v_div_scale leaves y unscaled, which it does unless y, 1/y or x/y leave the normal range or x is tiny
+// (ISA: V_DIV_SCALE_F64). RTC_SHARED_NORMALIZE = 1 evaluates that part once when |mag| is in [2^-400, 2^400] and every
+// component is +-0 or at least 2^-500 in magnitude (then no scaling happens, VCC is clear and v_div_fmas is a plain fma):
+// 5 + 3 x 4 instructions + the guards instead of 33, bit-identical (tests/test_gpu_round3.py: rtc_device_arith op 5 vs op 6
+// vs the host, 2 M triples). Measured (profiles/r03_exp_shared_normalize.log): no gain in k_trace (north star equal, C4 +1 %), so 0 there;
+// the binning kernel uses it (primary_dir).
+#ifndef RTC_SHARED_NORMALIZE
+#define RTC_SHARED_NORMALIZE 0
+#endif
+DEVI V3 vnormalize_shared(V3 a) {
+    const double mag = sqrt(a.x * a.x + a.y * a.y + a.z * a.z);
+    auto in_range = [](double v) { return __builtin_amdgcn_class(v, 0x060 /* +-0 */) || fabs(v) >= 0x1p-500; };
+    if (fabs(mag) >= 0x1p-400 && fabs(mag) <= 0x1p400 && in_range(a.x) && in_range(a.y) && in_range(a.z)) {
+        const double r0 = __builtin_amdgcn_rcp(mag);
+        const double e0 = __builtin_fma(-mag, r0, 1.0);
+        const double r1 = __builtin_fma(r0, e0, r0);
+        const double e1 = __builtin_fma(-mag, r1, 1.0);
+        const double r = __builtin_fma(r1, e1, r1);
+        auto quot = [&](double x) {
+            const double q = x * r;
+            const double rem = __builtin_fma(-mag, q, x);
+            return __builtin_amdgcn_div_fixup(__builtin_fma(rem, r, q), mag, x);
+        };
+        return mk(quot(a.x), quot(a.y), quot(a.z));
+    }
+    return mk(a.x / mag, a.y / mag, a.z / mag);
+}
+DEVI V3 vnormalize(V3 a) {
+#if RTC_SHARED_NORMALIZE
+    return vnormalize_shared(a);
+#else
+    return vnormalize_plain(a);
+#endif
 }
 // Vector::reflect vec.rs:106-108: self - n*(2*(self.n))
 DEVI V3 vreflect(V3 v, V3 n) { return vsub(v, vmul(n, 2. * vdot(v, n))); }
@@ -2004,6 +2040,14 @@ __global__ void __launch_bounds__(256) k_prep_primary(const DevIsect *isect, Dev
 __global__ void k_arith(uint32_t op, const double *a, const double *b, uint32_t n, double *out) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    if (op == 5u || op == 6u) { // Vector::normalize of the triple (a[3t], a[3t+1], a[3t+2]): 5 = the shared-divisor form, 6 = three divisions
+        if (i % 3u == 0u && i + 2u < n) {
+            const V3 v = mk(a[i], a[i + 1], a[i + 2]);
+            const V3 r3 = op == 5u ? vnormalize_shared(v) : vnormalize_plain(v);
+            out[i] = r3.x; out[i + 1] = r3.y; out[i + 2] = r3.z;
+        }
+        return;
+    }
     double r;
     switch (op) {
     case 0: r = sqrt(a[i]); break;
@@ -2024,7 +2068,9 @@ DEVI V3 primary_dir(const DevCamera &C, V3 cam_origin, uint32_t px, uint32_t py,
     const double world_x = C.half_width - xoffset;
     const double world_y = C.half_height - yoffset;
     const V3 pixel = xpoint(C.vinv, mk(world_x, world_y, -1.));
-    return vnormalize(vsub(pixel, cam_origin));
+    // the shared-divisor form (bit-identical, and a cone does not even need that): the binning kernel's lanes normalise ten
+    // corner rays each on one latency-bound chain — C3's pipelined frame -7 % (profiles/r03_exp_shared_normalize.log)
+    return vnormalize_shared(vsub(pixel, cam_origin));
 }
 
 struct BinParams {

@@ -235,3 +235,29 @@ def test_forced_one_level_cull_beyond_256_objects(rtc, scenes):
         assert c.last_launch_info()["source"] == 3
         assert np.array_equal(got, want) and st == st0, env
         c.close()
+
+
+def test_shared_divisor_normalize_is_bit_identical(gpu):
+    """Vector::normalize (vec.rs:65-76) with the three divisions sharing the divisor-only part of hipcc's f64 division
+    expansion (rtc_kernels.hip vnormalize_shared, behind RTC_SHARED_NORMALIZE; an experiment) must equal three IEEE divisions
+    bit for bit — and both must equal the host: ordinary directions, zeros and signed zeros, tiny and huge components (the
+    guard's fall-back), denormals, infinities."""
+    rng = np.random.default_rng(11)
+    n = 2_000_000
+    v = rng.normal(size=(n, 3))
+    v[:200000] *= np.exp(rng.uniform(-700, 700, (200000, 1)))            # whole vectors far outside the guard's range
+    v[200000:400000] *= np.exp(rng.uniform(-60, 60, (200000, 3)))        # components of very different size
+    v[400000:500000, rng.integers(0, 3)] = 0.0
+    v[500000:520000] = np.where(rng.random((20000, 3)) < 0.5, 0.0, -0.0) + rng.normal(size=(20000, 3)) * (rng.random((20000, 3)) < 0.4)
+    v[520000:540000] *= 1e-310                                             # denormals
+    v[540000:540010] = [[np.inf, 1, 1], [1, -np.inf, 0], [0, 0, 0], [-0.0, 0.0, -0.0], [np.nan, 1, 2], [1e308, 1e308, 1e308],
+                        [5e-324, 0, 0], [1, 5e-324, 0], [2.0 ** -500, 2.0 ** -501, 1], [2.0 ** 400, 2.0 ** 400, 0]]
+    flat = np.ascontiguousarray(v.reshape(-1))
+    shared = gpu.device_arith(5, flat)
+    plain = gpu.device_arith(6, flat)
+    assert np.array_equal(shared.view(np.uint64), plain.view(np.uint64))
+    with np.errstate(all="ignore"):
+        mag = np.sqrt(v[:, 0] * v[:, 0] + v[:, 1] * v[:, 1] + v[:, 2] * v[:, 2])
+        host = v / mag[:, None]
+    ok = (plain.reshape(-1, 3).view(np.uint64) == host.view(np.uint64)) | (np.isnan(plain.reshape(-1, 3)) & np.isnan(host))
+    assert ok.all()
