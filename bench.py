@@ -5,7 +5,7 @@ Metric (BASELINE.json): Mrays/sec (primary+shadow), 1920x1080 x 100 spheres; 1/2
 A step = one frame = ONE call of Camera::render_async(&World) -> Canvas (camera.rs:144-160; the reference's Criterion
 bench calls it in a loop on one camera, benches/render.rs:63-85): ONE camera per launch, every frame into a fresh device
 canvas (a ring of --canvases f64 canvases: render_async returns a new Canvas per call), World resident in HBM. The context
-is pipelined (rtc_context_set_pipeline, --pipeline 2): consecutive launches go to alternating streams, so launch i+1
+is pipelined (rtc_context_set_pipeline, --pipeline 3): consecutive launches go round-robin to three streams, so launch i+1
 fills the CUs launch i's last waves leave idle and its binning kernel runs beside launch i's render.
 
 --gpus N: the frame is row-tiled behind the C-ABI (rtc_group, include/rtc.h) — 8-row bands dealt round-robin over one
@@ -78,7 +78,7 @@ def parse():
     ap.add_argument("--spheres", type=int, default=-1)
     ap.add_argument("--no-plane", action="store_true")
     ap.add_argument("--reflective", action="store_true")
-    ap.add_argument("--pipeline", type=int, default=2, help="N = 1: streams the context deals consecutive launches over (1 = in order on one stream)")
+    ap.add_argument("--pipeline", type=int, default=3, help="N = 1: streams the context deals consecutive launches over (1 = in order on one stream)")
     ap.add_argument("--canvases", type=int, default=4, help="N = 1: device canvases the frames rotate through (>= --pipeline)")
     ap.add_argument("--views-per-launch", type=int, default=1,
                     help="cameras per launch in the HEADLINE loop (1 = the reference's call shape; > 1 = rtc_render_views with that many "

@@ -404,6 +404,8 @@ typedef struct rtc_launch_info {
     uint32_t lane;        /* pipeline lane the launch went to (0 when depth = 1)                                    */
     uint32_t block;       /* threads per workgroup                                                                  */
     uint32_t lds_bytes;   /* dynamic LDS per workgroup (LDS-staged object tables, AA sample store)                  */
+    uint32_t tiles_per_workgroup; /* tiles one workgroup renders in sequence (1 unless RTC_TILES_PER_WG says otherwise)   */
+    uint32_t _reserved[3];
 } rtc_launch_info;
 rtc_status  rtc_context_last_launch_info(rtc_context *ctx, rtc_launch_info *out);
 

@@ -414,7 +414,8 @@ class Context:
         _check(lib().rtc_context_last_launch_info(self._h, C.byref(i)), "rtc_context_last_launch_info")
         return {"source": i.source, "source_name": SOURCE_NAMES.get(i.source, "?"), "reflective": bool(i.reflective),
                 "refractive": bool(i.refractive), "binned_primary_pass": bool(i.binned), "light_lists": bool(i.light_lists),
-                "lane": i.lane, "threads_per_workgroup": i.block, "dynamic_lds_bytes": i.lds_bytes}
+                "lane": i.lane, "threads_per_workgroup": i.block, "dynamic_lds_bytes": i.lds_bytes,
+                "tiles_per_workgroup": i.tiles_per_workgroup}
 
     def binning_times_ms(self, last: int = 1024) -> np.ndarray:
         """Durations (ms) of the binning kernels of the most recent `last` timed launches (0 where a launch had none)."""

@@ -51,7 +51,8 @@ class RtcHit(C.Structure):
 
 class RtcLaunchInfo(C.Structure):
     _fields_ = [("source", C.c_uint32), ("reflective", C.c_uint32), ("refractive", C.c_uint32), ("binned", C.c_uint32),
-                ("light_lists", C.c_uint32), ("lane", C.c_uint32), ("block", C.c_uint32), ("lds_bytes", C.c_uint32)]
+                ("light_lists", C.c_uint32), ("lane", C.c_uint32), ("block", C.c_uint32), ("lds_bytes", C.c_uint32),
+                ("tiles_per_workgroup", C.c_uint32), ("_reserved", C.c_uint32 * 3)]
 
 
 SOURCE_NAMES = {0: "brute force, records through the scalar cache", 1: "brute force, object table staged in LDS (one tile)",

@@ -194,6 +194,8 @@ struct RenderParams {
     void *hits; // rtc_hit[nrays] or nullptr
     uint32_t grid_x, grid_y; // logical block grid of the render
     uint32_t flags;          // RTC_FLAG_*
+    uint32_t total_blocks;   // tiles (x views) of the launch; a workgroup renders tiles blockIdx.x + k * gridDim.x, k < reps
+    uint32_t reps;
     uint32_t band_stride;    // tile row k of the grid renders image rows y0 + 8*k*band_stride .. (+8) and
                              // writes output rows 8*k .. (+8): 1 = a contiguous range of rows, N = every
                              // N-th band of 8 rows (interleaved row tiles, rtc_render_bands)

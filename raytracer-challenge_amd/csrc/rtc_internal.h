@@ -35,6 +35,7 @@ struct rtc_context {
     unsigned char *d_canvas8 = nullptr; // the same for rtc_render_rgb8 (3 B/pixel)
     size_t canvas8_bytes = 0;
     int force_src = -1;   // RTC_SRC env override (experiments)
+    uint32_t tiles_per_wg = 1; // tiles one workgroup renders in sequence (RTC_TILES_PER_WG)
     uint32_t tile_cap = 512;
     hipStream_t side_stream = nullptr; // created on demand: per-render binning kernels run here, beside the previous launch's render
     // Pipelined launches (rtc_context_set_pipeline, include/rtc.h): `lanes` > 1 deals consecutive render launches round-robin

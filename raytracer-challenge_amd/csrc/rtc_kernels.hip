@@ -1116,8 +1116,20 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     const uint32_t wave = threadIdx.x >> 6;
     constexpr bool probe = PROBE;
 
+    if constexpr (SRC == SRC_LDS1) { // the whole object table, once per workgroup
+        stage_tile(T, L, 0, P.n);
+        __syncthreads();
+    }
+    uint32_t c_primary = 0, c_shadow = 0, c_reflect = 0, c_refract = 0; // wave-uniform
+    uint32_t c_resample = 0;            // wave-uniform: pixels that tripped the resample test
+    // A workgroup renders `reps` tiles, one after the other: tile ids blockIdx.x, blockIdx.x + gridDim.x, ... (consecutive
+    // workgroups still land on consecutive XCDs). The canvas stores of tile k then drain while tile k+1 is traced (a wave cannot
+    // retire before its stores are acknowledged), and the per-wave set-up and the counter atomics are paid once per `reps` tiles.
+    const uint32_t reps = PROBE ? 1u : P.reps;
+    for (uint32_t rep = 0; rep < reps; ++rep) {
     // workgroup id -> tile: see RTC_TILE_ORDER (XCD balance beats XCD locality here)
-    uint32_t bid = blockIdx.x;
+    uint32_t bid = blockIdx.x + rep * gridDim.x;
+    if (!PROBE && bid >= P.total_blocks) break; // (workgroup-uniform)
 #if RTC_TILE_ORDER == 0
     {
         const uint32_t nb = gridDim.x, q = nb / 8u, r = nb % 8u, xcd = bid % 8u, k = bid / 8u;
@@ -1145,13 +1157,6 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
         traced = in_range && !(P.mode == RTC_MODE_RENDER && (px + 1u >= P.W || py + 1u >= P.H));
     }
 
-    if constexpr (SRC == SRC_LDS1) {
-        stage_tile(T, L, 0, P.n);
-        __syncthreads();
-    }
-
-
-    uint32_t c_primary = 0, c_shadow = 0, c_reflect = 0, c_refract = 0; // wave-uniform
 #ifdef RTC_STAMPS
     unsigned long long stamp_t[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long stamp_last = __builtin_amdgcn_s_memtime();
@@ -1195,7 +1200,6 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     const bool aa = !probe && P.samples != 1u;
     uint32_t nsamples = aa ? 4u : 1u;   // grows to 4 + resample_n after sample 3 when some lane resamples
     bool lane_resample = false;         // this lane's pixel tripped the test AND the resample is enabled
-    uint32_t c_resample = 0;            // wave-uniform: pixels that tripped the test
     // per thread: the four sub-samples (12 doubles) and Color::average_over's running sums (3 doubles)
     double *aa_store = reinterpret_cast<double *>(reinterpret_cast<char *>(lds_raw) + P.aa_lds_off) + threadIdx.x * 15u;
     V3 result = mk(0., 0., 0.);
@@ -1996,6 +2000,12 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
         }
     }
 
+    if (rep + 1u < reps) {
+        // the next tile is staged over the same LDS: the workgroup's cooperative store must have read it (a wave's own LDS
+        // operations are in order, so the per-wave output form needs nothing)
+        if constexpr (!PROBE && !RTC_WAVE_OUTPUT(REFL)) __syncthreads();
+    }
+    } // rep
     STAMP(7); // shaded, stored
     const auto &Pc = KP(P_arg);
 #ifdef RTC_DIAG_NO_COUNTERS

@@ -440,7 +440,7 @@ def test_bench_single_gpu_line():
                         "--width", "640", "--height", "360"], capture_output=True, text=True, timeout=300, cwd=root)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
-    assert line["config"]["frames_per_launch"] == 1 and line["config"]["pipeline_streams"] == 2 and "ONE camera" in line["config"]["call_shape"]
+    assert line["config"]["frames_per_launch"] == 1 and line["config"]["pipeline_streams"] == 3 and "ONE camera" in line["config"]["call_shape"]
     rf = line["roofline"]
     assert rf["frames_per_launch"] == 1 and rf["kernel_launches_timed"] == 24 and 0 < rf["frac"] < 1
     assert rf["algorithmic_bytes_per_launch"] == 24 * 640 * 360 + 400 * 101 + 128 + 200

@@ -1,13 +1,6 @@
-# Interleaved A/B of two ENVIRONMENT settings on one build and one box:
-#   bash tools/ab_env.sh "<workloads>" "<env A>" "<env B>" [reps] [extra bench args]
+# Interleaved A/B of environment settings on ONE build and box: bash tools/ab_env.sh "<workloads>" "<env A>|<env B>|..." [reps] ["bench args"]
 cd $GRAFT_REPO_ROOT
-WL=$1; EA=$2; EB=$3; REPS=${4:-3}; EXTRA=${5:---steps 96 --warmup 16}
-for w in $WL; do
-  for r in $(seq $REPS); do
-    for v in "$EA" "$EB"; do
-      env $v timeout -k 10 120 python bench.py --workload $w $EXTRA --lean 2>/dev/null | python3 -c "
-import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$w', '$v', 'kernel/frame', d['roofline']['kernel_ms_per_frame'], 'ms/frame', d['ms_per_step'])" || echo "$w $v failed"
-    done
-  done
-done
+WL=$1; IFS='|' read -ra ENVS <<< "$2"; REPS=${3:-3}; ARGS=${4:-"--steps 200 --warmup 8"}
+for w in $WL; do for r in $(seq $REPS); do for e in "${ENVS[@]}"; do
+  env $e timeout -k 10 200 python bench.py --workload $w $ARGS --lean 2>/dev/null | python3 tools/_line.py "$w [$e]" ms_per_step roofline.kernel_ms_avg || echo "$w [$e] failed"
+done; done; done
