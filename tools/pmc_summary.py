@@ -28,7 +28,16 @@ try:
             line = json.loads(l)
 except Exception:
     pass
-res = {"kernel_trace": kern, "per_launch_averages": avg}
+import os
+res = {"head": os.environ.get("HEAD_SHA"), "command": "rocprofv3 --kernel-trace [--stats | --pmc <group>] -- python3 bench.py --profile-leg --steps N [--workload W]",
+       "kernel_trace": kern, "per_launch_averages": avg}
+# the launch's other kernels (k_bin_tiles: the binning kernel in front of every binned launch)
+others = {}
+for f in glob.glob(out + "/stats/**/*kernel_stats.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        if "k_trace" not in r["Name"] and r["Name"].startswith(("k_", "void k_")):
+            others[r["Name"][:60]] = {"calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"])}
+res["other_kernels"] = others
 V = line["config"]["frames_per_launch"] if line else 1
 if line:
     res["workload_key"] = line["config"].get("workload_key")
