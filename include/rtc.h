@@ -169,7 +169,11 @@ typedef struct rtc_stats {
     uint64_t pixels;         /* pixels written by the last render                        */
     uint64_t pixels_resample;/* pixels whose 4 sub-samples trip the resample test
                                 (camera.rs:108-111); 0 when samples == 1                 */
-    uint64_t _reserved[2];
+    uint64_t rays_primary_proven_miss; /* of rays_primary: primary rays of image tiles the binning kernel PROVED to hit nothing
+                                (empty candidate list, cone clear of every plane): counted as cast — the reference casts
+                                them — but answered by the proof, no ray is generated for them (one-sample renders of
+                                binned launches; 0 otherwise)                                  */
+    uint64_t _reserved[1];
 } rtc_stats;
 
 /* Per-ray probe record filled by rtc_color_at: the fields of CachedVectors

@@ -375,10 +375,15 @@ class Context:
     def upload(self, world: World) -> "DeviceWorld":
         return DeviceWorld(self, world)
 
-    def stats(self) -> dict:
+    def stats(self, extended: bool = False) -> dict:
+        """Ray counters since the last reset. extended=True adds `rays_primary_proven_miss` (of rays_primary: primary rays of
+        tiles the binning kernel proved black — counted as cast, answered without generating a ray; include/rtc.h)."""
         s = RtcStats()
         _check(lib().rtc_stats_read(self._h, C.byref(s)), "rtc_stats_read")
-        return _stats_dict(s)
+        d = _stats_dict(s)
+        if extended:
+            d["rays_primary_proven_miss"] = s.rays_primary_proven_miss
+        return d
 
     def reset_stats(self):
         _check(lib().rtc_stats_reset(self._h), "rtc_stats_reset")

@@ -40,7 +40,8 @@ class RtcCamera(C.Structure):
 
 class RtcStats(C.Structure):
     _fields_ = [("rays_primary", C.c_uint64), ("rays_shadow", C.c_uint64), ("rays_reflect", C.c_uint64),
-                ("rays_refract", C.c_uint64), ("pixels", C.c_uint64), ("pixels_resample", C.c_uint64), ("_reserved", C.c_uint64 * 2)]
+                ("rays_refract", C.c_uint64), ("pixels", C.c_uint64), ("pixels_resample", C.c_uint64), ("rays_primary_proven_miss", C.c_uint64),
+                ("_reserved", C.c_uint64 * 1)]
 
 
 class RtcHit(C.Structure):

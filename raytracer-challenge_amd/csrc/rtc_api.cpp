@@ -262,6 +262,7 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
     }
     if (const char *e = std::getenv("RTC_BINNING")) ctx->binning = std::atoi(e) != 0;
     if (const char *e = std::getenv("RTC_LIGHT_LISTS")) ctx->light_lists = std::atoi(e) != 0;
+    if (const char *e = std::getenv("RTC_SKY_ROWS")) ctx->sky_rows = std::atoi(e) != 0;
     if (const char *e = std::getenv("RTC_BIN_SMALL_PIXELS")) ctx->bin_small_pixels = std::strtoull(e, nullptr, 10);
     if (const char *e = std::getenv("RTC_BIN_SMALL_PIXELS_PIPELINED")) ctx->bin_small_pixels_pipelined = std::strtoull(e, nullptr, 10);
     if (const char *e = std::getenv("RTC_TILES_PER_WG")) {
@@ -685,7 +686,7 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
             if (B.tile_list) (void)hipFree(B.tile_list);
             B.tile_cnt = nullptr; B.tile_list = nullptr; B.tiles_cap = 0;
             ++ctx->render_allocs;
-            const bool got = hipMalloc(&B.tile_cnt, sizeof(uint32_t) * tiles) == hipSuccess &&
+            const bool got = hipMalloc(&B.tile_cnt, sizeof(uint32_t) * (tiles + RTC_BIN_ROW_WORDS)) == hipSuccess &&
                              (++ctx->render_allocs, hipMalloc(&B.tile_list, sizeof(uint32_t) * tiles * RTC_TILE_LIST_CAP) == hipSuccess);
             if (got) B.tiles_cap = tiles;
             else { // the lists are an optimisation: without memory for them the launch walks (same pixels)
@@ -696,10 +697,12 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
             }
         }
         if (bin_ok) {
-            HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound_s, w->d_gbound, w->d_orig_s, w->ngroups, B.tile_cnt,
-                                       B.tile_list, y0 / 8u, band_stride, stream, timed ? pair_bin[0] : nullptr, timed ? pair_bin[1] : nullptr));
+            HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound_s, w->d_gbound, w->d_orig_s, w->ngroups,
+                                       B.tile_cnt + RTC_BIN_ROW_WORDS, B.tile_list, y0 / 8u, band_stride, stream, timed ? pair_bin[0] : nullptr,
+                                       timed ? pair_bin[1] : nullptr, w->d_isect_s, w->d_kind_s, w->n_unb, B.tile_cnt));
             if (timed) ctx->bin_timed[slot] = true;
-            P.tile_cnt = B.tile_cnt;
+            P.tile_rows = ctx->sky_rows ? B.tile_cnt : nullptr;
+            P.tile_cnt = B.tile_cnt + RTC_BIN_ROW_WORDS;
             P.tile_list = B.tile_list;
             P.tiles_x = tiles_x;
             P.tiles_y = tiles_y;
@@ -728,7 +731,7 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
                 S.tile_cnt = nullptr; S.tile_list = nullptr;
                 S.tiles_cap = 0;
                 ++ctx->render_allocs;
-                const bool got = hipMalloc(&S.tile_cnt, sizeof(uint32_t) * tiles_alloc) == hipSuccess &&
+                const bool got = hipMalloc(&S.tile_cnt, sizeof(uint32_t) * (tiles_alloc + RTC_BIN_ROW_WORDS)) == hipSuccess &&
                                  (++ctx->render_allocs, hipMalloc(&S.tile_list, sizeof(uint32_t) * tiles_alloc * RTC_TILE_LIST_CAP) == hipSuccess);
                 if (got) S.tiles_cap = tiles_alloc;
                 else {
@@ -746,12 +749,14 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
         // to the side stream: it runs beside the PREVIOUS launch's render kernel, which still reads the other set. It must
         // wait for the render kernel that last read THIS set (two launches ago); the render stream waits for the binning.
         HIP_TRY(hipStreamWaitEvent(ctx->side_stream, B.traced, 0)); // never recorded: no wait
-        HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound_s, w->d_gbound, w->d_orig_s, w->ngroups, B.tile_cnt,
-                                   B.tile_list, y0 / 8u, band_stride, ctx->side_stream, timed ? pair_bin[0] : nullptr, timed ? pair_bin[1] : nullptr));
+        HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound_s, w->d_gbound, w->d_orig_s, w->ngroups,
+                                   B.tile_cnt + RTC_BIN_ROW_WORDS, B.tile_list, y0 / 8u, band_stride, ctx->side_stream, timed ? pair_bin[0] : nullptr,
+                                   timed ? pair_bin[1] : nullptr, w->d_isect_s, w->d_kind_s, w->n_unb, B.tile_cnt));
         if (timed) ctx->bin_timed[slot] = true;
         HIP_TRY(hipEventRecord(B.binned, ctx->side_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, B.binned, 0));
-        P.tile_cnt = B.tile_cnt;
+        P.tile_rows = ctx->sky_rows ? B.tile_cnt : nullptr;
+        P.tile_cnt = B.tile_cnt + RTC_BIN_ROW_WORDS;
         P.tile_list = B.tile_list;
         P.tiles_x = tiles_x;
         P.tiles_y = tiles_y;
@@ -825,6 +830,7 @@ rtc_status rtc_stats_read(rtc_context *ctx, rtc_stats *out) {
     out->rays_refract = h[CNT_REFRACT];
     out->pixels = ctx->pixels; // counted at launch time (render_launch)
     out->pixels_resample = h[CNT_RESAMPLE];
+    out->rays_primary_proven_miss = h[CNT_SKY];
     return RTC_OK;
 }
 

@@ -97,7 +97,7 @@ struct DevTileBundle {
 // is r * (1 + k * D * (cn + D)) with k = 0.75e-14 * ||A||_F^2 (any upper bound of D may be used).
 // For ordinary scenes the factor is 1 + 1e-9.
 
-enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PIXELS = 4, CNT_RESAMPLE = 5, CNT_STAMP0 = 8, CNT_DIAG0 = 16, CNT_STAMP2 = 32 /* the same phases, secondary passes only */, CNT_N = 40 };
+enum { CNT_PRIMARY = 0, CNT_SHADOW = 1, CNT_REFLECT = 2, CNT_REFRACT = 3, CNT_PIXELS = 4, CNT_RESAMPLE = 5, CNT_SKY = 6, CNT_STAMP0 = 8, CNT_DIAG0 = 16, CNT_STAMP2 = 32 /* the same phases, secondary passes only */, CNT_N = 40 };
 // Ray counters are kept in CNT_SLOTS replicas (one 64-byte line each); a wave adds to the replica
 // picked by its workgroup id, so no single word sees more than 1/CNT_SLOTS of the atomics. The host
 // sums the replicas (rtc_stats_read).
@@ -162,6 +162,7 @@ struct RenderParams {
     // RTC_TILE_LIST_CAP insertion indices, image tile (tx, ty) of view v at (v * tiles_y + ty) * tiles_x + tx
     const uint32_t *tile_cnt;
     const uint32_t *tile_list;
+    const uint32_t *tile_rows; // per view two words: the smallest, and ~ the largest, tile row with a tile NOT proven black (k_bin_tiles)
     uint32_t tiles_x, tiles_y;
     // light-space shadow lists (nullptr: none): per direction cell a counter and RTC_LIGHT_LIST_CAP insertion indices
     const uint32_t *light_cnt;

@@ -52,6 +52,7 @@ struct rtc_context {
     hipEvent_t fence_ev = nullptr; // rtc_context_fence
     bool light_lists = true; // RTC_LIGHT_LISTS=0: shadow passes of two-level worlds walk the groups (A/B)
     bool binning = true;  // RTC_BINNING=0: primary rays take the wave-level cull / group walk too (A/B)
+    bool sky_rows = true; // RTC_SKY_ROWS=0: tile rows the binning kernel proved black are traced like any other (A/B)
     // one-level worlds (<= 256 objects) are binned only in launches of at least this many views (RTC_BIN_SMALL_VIEWS): the
     // binning kernels run on the side stream beside the previous launch's render, which hides them when launches follow each
     // other (north star, 8 views per launch: 0.0745 -> 0.0685 ms per frame; 4 views: 0.0732 -> 0.0704; C4 1.48 -> 1.42;
@@ -85,7 +86,7 @@ struct rtc_world {
     // binned primary pass: per-render scratch, grow-only, TWO sets — the binning of launch k+1 runs on the context's side
     // stream while launch k's render kernel still reads set k (rtc_render_* take the World as const: mutable)
     struct BinSet {
-        uint32_t *tile_cnt = nullptr, *tile_list = nullptr; // per (view, tile): entries used, RTC_TILE_LIST_CAP entry slots
+        uint32_t *tile_cnt = nullptr, *tile_list = nullptr; // per (view, tile): entries used, RTC_TILE_LIST_CAP entry slots (tile_cnt: RTC_BIN_ROW_WORDS row words first)
         size_t tiles_cap = 0;            // capacity in (view, tile) entries
         hipEvent_t binned = nullptr;     // recorded on the side stream after the set's binning kernel
         hipEvent_t traced = nullptr;     // recorded on the render stream after the render kernel that read the set
@@ -106,7 +107,9 @@ struct rtc_world {
 
 extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound_s,
                                          const DevBound *gbound, const uint32_t *orig_s, uint32_t ngroups, uint32_t *cnt, uint32_t *list,
-                                         uint32_t row0, uint32_t row_stride, hipStream_t stream, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+                                         uint32_t row0, uint32_t row_stride, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
+                                         const DevIsect *isect_s, const uint32_t *kind_s, uint32_t n_unb, uint32_t *rows);
+enum { RTC_BIN_ROW_WORDS = 2 * RTC_MAX_VIEWS }; // a BinSet's tile_cnt buffer starts with the views' row words (RenderParams::tile_rows)
 extern "C" hipError_t rtc_launch_light_lists(uint32_t n, uint32_t cap, const DevBound *bound, const double light[3], double reach, DevTileBundle *cells,
                                              DevTileBundle *macros, uint32_t *cnt, uint32_t *list, hipStream_t stream);
 extern "C" hipError_t rtc_launch_undeal(const void *staging, void *canvas, uint32_t nranks, uint32_t nframes, uint32_t H,

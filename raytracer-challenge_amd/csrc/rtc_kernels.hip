@@ -1122,6 +1122,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     }
     uint32_t c_primary = 0, c_shadow = 0, c_reflect = 0, c_refract = 0; // wave-uniform
     uint32_t c_resample = 0;            // wave-uniform: pixels that tripped the resample test
+    uint32_t c_sky = 0;                 // wave-uniform: primary rays of tiles proven black (sky_tile)
     // A workgroup renders `reps` tiles, one after the other: tile ids blockIdx.x, blockIdx.x + gridDim.x, ... (consecutive
     // workgroups still land on consecutive XCDs). The canvas stores of tile k then drain while tile k+1 is traced (a wave cannot
     // retire before its stores are acknowledged), and the per-wave set-up and the counter atomics are paid once per `reps` tiles.
@@ -1167,6 +1168,19 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     unsigned diag_c[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     STAMP(0);
+
+    // Tile rows the binning kernel PROVED black for this view (k_bin_tiles, `rows`): no ray is generated, no pass is run, the
+    // tile is stored as Canvas::new left it; the primary rays the reference would have cast are still counted (and reported
+    // separately, rtc_stats::rays_primary_proven_miss). One-sample renders only.
+    bool sky_tile = false;
+    if constexpr (IS_CULL(SRC) && !PROBE) {
+        const auto &Pt = KP(P_arg);
+        if (Pt.tile_rows != nullptr && Pt.samples == 1u) {
+            const uint32_t ity = (Pt.y0 >> 3) + (tbid / Pt.grid_x) * Pt.band_stride;
+            const uint32_t first = Pt.tile_rows[2u * view], lastinv = Pt.tile_rows[2u * view + 1u];
+            sky_tile = ity < first || ity > ~lastinv; // (no tile of the view is non-empty: first = 0xffffffff)
+        }
+    }
 
     // Binned primary pass: this wave's 8x8 tile has a list of the objects its primary rays can touch (k_bin_tiles): lane e
     // holds entry e. (RTC_BIN_HOIST: the 64 entry slots of a tile always exist, the ones past the
@@ -1224,6 +1238,9 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             ro = mk(rp[0], rp[1], rp[2]);
             rd = mk(rp[3], rp[4], rp[5]);
             shared_origin = false;
+        } else if (sky_tile) { // proven black: no ray is needed
+            ro = cam_origin; rd = mk(0., 0., 1.);
+            shared_origin = true;
         } else {
             // Camera::ray_for_pixel_offset camera.rs:64-76; sub-sample offsets camera.rs:98,102-105
             double xo = 0.5, yo = 0.5;
@@ -1246,6 +1263,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
         int rem = (int)P.remaining;
         int sp = 0;
         c_primary += popc64(ballot(tracing));
+        if (sky_tile) { c_sky += popc64(ballot(tracing)); tracing = false; } // counted as cast (the reference casts them), answered by the proof
 
         // Worlds without reflective / transparent materials (REFL == false) need exactly one pass per
         // primary ray; otherwise loop until every lane's frame stack has unwound.
@@ -1255,7 +1273,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             lstk[0] = 0.; lstk[BLOCK] = 0.; lstk[2 * BLOCK] = 0.;
         }
         uint32_t k3_pass = 0;
-        for (bool pass_again = true; pass_again;) {
+        for (bool pass_again = !sky_tile; pass_again;) {
             if constexpr (COMPACT) {
                 // K3 — wavefront compaction between bounces. The workgroup's two waves publish how many rays each still
                 // traces (__ballot + popcount); once both have some and together they fit one wave, the wave with fewer
@@ -2020,6 +2038,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             if (c_reflect) atomicAdd(slot + CNT_REFLECT, (unsigned long long)c_reflect);
             if (c_refract) atomicAdd(slot + CNT_REFRACT, (unsigned long long)c_refract);
             if (c_resample) atomicAdd(slot + CNT_RESAMPLE, (unsigned long long)c_resample);
+            if (c_sky) atomicAdd(slot + CNT_SKY, (unsigned long long)c_sky);
 #ifdef RTC_STAMPS
             for (int i = 0; i < 8; ++i) atomicAdd(slot + CNT_STAMP0 + i, stamp_t[i]);
             for (int i = 0; i < 8; ++i) atomicAdd(slot + CNT_STAMP2 + i, stamp_t[8 + i]);
@@ -2160,9 +2179,33 @@ DEVI uint32_t bin_entry(const BinParams &Q, V3 o, const DevBound &b, uint32_t j)
 // wave per (view, object), atomic appends, a second kernel for objects that cover many tiles, a third for the cones: the
 // same lists at 3x the launches; C3 -2 %, C5 -3 %, one camera per launch C3 -11 % for this form,
 // profiles/r02_exp_pull_binning.log.)
+// Can NO ray of the cone `t` around apex `o` hit the plane whose stored inverse has the rows m[0..11]? Plane::intersect_local
+// (shape.rs:462-471): none when |d'.y| < EPSILON, else t = -o'.y / d'.y, a hit iff t >= 0 — i.e. iff o'.y and d'.y differ in
+// sign (or the quotient underflows to -0.0, which `t >= 0.0` accepts: |o'.y| >= 2^-500 and |r| <= 2^500 rule that out, as in
+// plane_t_certainly_negative). o'.y is the same for every ray of the view (shared origin; evaluated as the kernel does); d'.y
+// = r . d with r = (m4, m5, m6) and d a unit vector within theta of the axis a: s * (r . d) >= s*(r.a) cos(theta) - |r x a|
+// sin(theta) when s*(r.a) > 0. Proven a miss when that lower bound clears 1e-4 |r| (the axis is unit to 2e-6, cos / sin carry
+// cell_cone's margins, the reference's own roundings are 1e-16).
+DEVI bool cone_misses_plane(const double *m, V3 o, const DevTileBundle &t) {
+#pragma clang fp contract(fast) // cull arithmetic
+    if (t.off != 0u) return false;
+    const double oy = m[4] * o.x + m[5] * o.y + m[6] * o.z + m[7];
+    if (!(fabs(oy) >= 0x1p-500) || !(fabs(oy) < __builtin_inf())) return false; // (0, NaN, inf: no proof)
+    const double s = oy > 0. ? 1. : -1.;
+    const double rx = m[4], ry = m[5], rz = m[6];
+    const double rr = rx * rx + ry * ry + rz * rz;
+    if (!(rr > 0x1p-900) || !(rr < 0x1p900)) return false;
+    const double ra = s * (rx * (double)t.ax + ry * (double)t.ay + rz * (double)t.az);
+    if (!(ra > 0.)) return false;
+    const double perp = __builtin_sqrt(fmax(0., rr - ra * ra) * 1.00001 + 1e-10 * rr);
+    const double lower = ra * (double)t.cosT * 0.99999 - perp * (double)t.sinT;
+    return lower > 1e-4 * __builtin_sqrt(rr);
+}
+
 __global__ void __launch_bounds__(64) k_bin_tiles(const BinParams Q, const DevBound *__restrict__ bound_s, const DevBound *__restrict__ gbound,
                                                    const uint32_t *__restrict__ orig_s, uint32_t ngroups, uint32_t *__restrict__ cnt,
-                                                   uint32_t *__restrict__ list) {
+                                                   uint32_t *__restrict__ list, const DevIsect *__restrict__ isect_s,
+                                                   const uint32_t *__restrict__ kind_s, uint32_t n_unb, uint32_t *__restrict__ rows) {
     const uint32_t macros = Q.macros_x * Q.macros_y;
     const uint32_t view = blockIdx.x / macros, m = blockIdx.x % macros, lane = threadIdx.x;
     const uint32_t mx = m % Q.macros_x, my = m / Q.macros_x;
@@ -2173,7 +2216,8 @@ __global__ void __launch_bounds__(64) k_bin_tiles(const BinParams Q, const DevBo
     V3 o = xpoint(C.vinv, mk(0., 0., 0.));
     o = mk(uniform_f64(o.x), uniform_f64(o.y), uniform_f64(o.z));
     const Bundle MB = bundle_of(cell_cone(Q, view, mx * 64u, my * 64u, 64u), o);
-    const Bundle TB = bundle_of(cell_cone(Q, view, min(tx, Q.tiles_x - 1u) * 8u, min(ty, Q.tiles_y - 1u) * 8u, 8u), o);
+    const DevTileBundle tcone = cell_cone(Q, view, min(tx, Q.tiles_x - 1u) * 8u, min(ty, Q.tiles_y - 1u) * 8u, 8u);
+    const Bundle TB = bundle_of(tcone, o);
     const size_t tile = (size_t)(view * Q.tiles_y + min(ty, Q.tiles_y - 1u)) * Q.tiles_x + min(tx, Q.tiles_x - 1u);
     uint32_t *my_list = list + tile * RTC_TILE_LIST_CAP;
     uint32_t my_cnt = 0;
@@ -2206,12 +2250,32 @@ __global__ void __launch_bounds__(64) k_bin_tiles(const BinParams Q, const DevBo
         }
     }
     if (mine) cnt[tile] = my_cnt; // > RTC_TILE_LIST_CAP: the list is incomplete and the render wave walks instead
+    // Tile rows that are PROVABLY BLACK for this view: a tile whose list is empty and whose cone misses every unbounded object
+    // (planes: cone_misses_plane; anything else unbounded: no proof) has no primary hit at any pixel — Camera::render writes
+    // background_color there (shape.rs:702-710, 652-653) whatever the rays' exact directions. rows[2v] = the smallest,
+    // ~rows[2v + 1] the largest tile row with a tile that is NOT proven empty (both preset to 0xffffffff): the render kernel
+    // skips ray generation and every pass for the tile rows outside that range (the sky of a floor scene: a third of the north star).
+    bool nonempty = mine;
+    if (mine && my_cnt == 0u && n_unb <= 4u) {
+        bool proven = true;
+        for (uint32_t k = 0; k < n_unb && proven; ++k)
+            proven = kind_s[k] == RTC_PLANE && cone_misses_plane(isect_s[k].m, o, tcone);
+        nonempty = !proven;
+    }
+    const uint32_t rmin = ~wave_max_u32(nonempty ? ~ty : 0u), rmaxinv = ~wave_max_u32(nonempty ? ty : 0u);
+    const bool any_nonempty = ballot(nonempty) != 0ull; // (evaluated by the whole wave, not under the lane-0 branch)
+    if (lane == 0u && any_nonempty) {
+        atomicMin(rows + 2u * view, rmin);
+        atomicMin(rows + 2u * view + 1u, rmaxinv);
+    }
 }
 
 extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound_s,
                                          const DevBound *gbound, const uint32_t *orig_s, uint32_t ngroups, uint32_t *cnt, uint32_t *list,
-                                         uint32_t row0, uint32_t row_stride, hipStream_t stream, hipEvent_t e0, hipEvent_t e1) {
+                                         uint32_t row0, uint32_t row_stride, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
+                                         const DevIsect *isect_s, const uint32_t *kind_s, uint32_t n_unb, uint32_t *rows) {
     if (n == 0) return hipSuccess;
+    if (hipMemsetAsync(rows, 0xff, sizeof(uint32_t) * 2u * RTC_MAX_VIEWS, stream) != hipSuccess) return hipGetLastError();
     BinParams Q;
     Q.row0 = row0; Q.row_stride = row_stride ? row_stride : 1u;
     for (uint32_t v = 0; v < nviews; ++v) Q.views[v] = views[v];
@@ -2221,7 +2285,8 @@ extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews
     Q.tiles_x = (W + 7u) / 8u; Q.tiles_y = (H + 7u) / 8u;
     Q.macros_x = (Q.tiles_x + 7u) / 8u; Q.macros_y = (Q.tiles_y + 7u) / 8u;
     // e0/e1 (may be NULL): the dispatch's own begin/end timestamps, as for k_trace
-    hipExtLaunchKernelGGL(k_bin_tiles, dim3(nviews * Q.macros_x * Q.macros_y), dim3(64), 0, stream, e0, e1, 0, Q, bound_s, gbound, orig_s, ngroups, cnt, list);
+    hipExtLaunchKernelGGL(k_bin_tiles, dim3(nviews * Q.macros_x * Q.macros_y), dim3(64), 0, stream, e0, e1, 0, Q, bound_s, gbound, orig_s, ngroups, cnt, list,
+                          isect_s, kind_s, n_unb, rows);
     return hipGetLastError();
 }
 

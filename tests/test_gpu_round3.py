@@ -261,3 +261,85 @@ def test_shared_divisor_normalize_is_bit_identical(gpu):
         host = v / mag[:, None]
     ok = (plain.reshape(-1, 3).view(np.uint64) == host.view(np.uint64)) | (np.isnan(plain.reshape(-1, 3)) & np.isnan(host))
     assert ok.all()
+
+
+def test_tile_rows_proven_black_are_skipped_exactly(rtc, scenes, O):
+    """k_bin_tiles proves tile rows black (empty candidate list + the tile's cone clear of every plane) and k_trace then
+    generates no ray for them: canvases, 8-bit frames and ray counts must equal the same render with the proof switched off
+    (RTC_SKY_ROWS=0), without binning (RTC_BINNING=0) and the oracle — floor scenes (sky above the horizon), no plane at all,
+    a wall behind the scene (no sky left: nothing may be skipped), a tilted floor, the camera under the floor, the camera ON
+    the plane (no proof possible), Camera::render's exclusive edge, bands, several views, a reflective world."""
+    import torch
+    M = rtc.Matrix
+    W, H = 320, 203
+
+    def world(kind):
+        w, cam = scenes.synthetic(60, W, H, with_plane=(kind != "noplane"), reflective=(kind == "reflective"))
+        if kind == "wall":
+            w.add_shape(rtc.plane(M.identity().rotation_x(math.pi / 2.0).translation(0.0, 0.0, 40.0), rtc.material(color=(0.4, 0.5, 0.7))))
+        if kind == "tilted":
+            w.shapes[-1] = rtc.plane(M.identity().rotation_z(0.2).rotation_x(-0.1), rtc.material(specular=0.0, pattern=("checker", (0.3,) * 3, (0.7,) * 3, None)))
+            w.shapes[-1].world_id = len(w.shapes)
+        if kind == "under":
+            cam = rtc.camera(W, H, 0.9, M.make_view_transform((0.0, -3.0, -8.0), (0.0, 2.0, 5.0), (0.0, 1.0, 0.0)))
+        if kind == "onplane":
+            cam = rtc.camera(W, H, 0.9, M.make_view_transform((0.0, 0.0, -8.0), (0.0, 1.0, 5.0), (0.0, 1.0, 0.0)))
+        if kind == "lookup":
+            cam = rtc.camera(W, H, 1.2, M.make_view_transform((0.0, 1.0, -8.0), (0.0, 9.0, 5.0), (0.0, 1.0, 0.0)))
+        return w, cam
+
+    expect_sky = {"floor": True, "noplane": True, "wall": False, "tilted": None, "under": None, "onplane": False, "lookup": True, "reflective": True}
+    for kind, sky in expect_sky.items():
+        w, cam = world(kind)
+        base = _ctx_env(rtc, RTC_BINNING=0)
+        want, st_want = base.upload(w).render(cam, with_stats=True)
+        base.close()
+        for env in (dict(RTC_BIN_SMALL_PIXELS=0), dict(RTC_BIN_SMALL_PIXELS=0, RTC_SKY_ROWS=0)):
+            ctx = _ctx_env(rtc, **env)
+            dw = ctx.upload(w)
+            for mode in (rtc.MODE_RENDER_ASYNC, rtc.MODE_RENDER):
+                ref_ctx = _ctx_env(rtc, RTC_BINNING=0)
+                ref, st_ref = ref_ctx.upload(w).render(cam, mode, with_stats=True)
+                ref_ctx.close()
+                f = torch.full((H, W, 3), -1.0, dtype=torch.float64, device="cuda:0")
+                q = torch.full((H, W, 3), 9, dtype=torch.uint8, device="cuda:0")
+                torch.cuda.synchronize()
+                ctx.reset_stats()
+                dw.render_rows(cam, 0, H, f.data_ptr(), mode, d_ptr8=q.data_ptr())
+                st = ctx.stats(extended=True)
+                proven = st.pop("rays_primary_proven_miss")
+                assert ctx.last_launch_info()["binned_primary_pass"]
+                assert np.array_equal(f.cpu().numpy(), ref) and st == st_ref, (kind, env, mode)
+                assert np.array_equal(q.cpu().numpy(), rtc.color_scale255(ref).reshape(H, W, 3)), (kind, env, mode)
+                if "RTC_SKY_ROWS" in env:
+                    assert proven == 0
+                elif sky is True:
+                    assert proven > 0 and proven % (W - (1 if mode == rtc.MODE_RENDER else 0)) == 0, (kind, proven)   # whole tile rows
+                    assert proven <= st["rays_primary"] - np.count_nonzero(ref.reshape(-1, 3).any(axis=1))      # never more than the black pixels
+                elif sky is False:
+                    assert proven == 0, (kind, proven)
+            # one rank's bands (rank 2 of 3) and three views in one launch
+            per = rtc.group_packed_rows(H, 3)
+            t = torch.zeros((per, W, 3), dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()
+            dw.render_bands(cam, 2, 3, t.data_ptr())
+            ctx.synchronize()
+            got = t.cpu().numpy()
+            for k in range(rtc.group_bands_owned(H, 3, 2)):
+                y0 = rtc.group_packed_row_to_image(2, 8 * k, 3)
+                assert np.array_equal(got[8 * k: 8 * k + min(8, H - y0)], want[y0:y0 + 8]), (kind, env, k)
+            cams = [cam, rtc.camera(W, H, 0.8, M.make_view_transform((1.0, 3.0, -9.0), (0.0, 0.5, 5.0), (0.0, 1.0, 0.0))), cam]
+            HP = -(-H // 8) * 8
+            v = torch.zeros((3 * HP, W, 3), dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()
+            dw.render_views(cams, 0, 1, v.data_ptr(), HP)
+            ctx.synchronize()
+            vh = v.cpu().numpy()
+            assert np.array_equal(vh[:H], want) and np.array_equal(vh[2 * HP:2 * HP + H], want), (kind, env)
+            other_ctx = _ctx_env(rtc, RTC_BINNING=0)
+            assert np.array_equal(vh[HP:HP + H], other_ctx.upload(w).render(cams[1])), (kind, env)
+            other_ctx.close()
+            dw.close()
+            ctx.close()
+        o_img, o_st = O.render(w.array(), len(w), w.light, cam, mode=1, nthreads=8, want_stats=True)
+        assert float(np.max(np.abs(o_img - want))) <= 1e-12 and o_st == st_want, kind
