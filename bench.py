@@ -321,7 +321,7 @@ def run_single(args, rtc, np, torch, dev, dev_index, world, cam, cam_arr, wkey, 
     ctx.reset_stats()
     ctx.set_timing(args.time_every)
     elapsed = timed(launch, sync, args.steps)
-    st = ctx.stats()
+    st = ctx.stats(extended=True)
     t_over = ctx.kernel_times_ms(1024)
     ctx.set_timing(0)
     steps = max(1, args.steps)
@@ -359,6 +359,9 @@ def run_single(args, rtc, np, torch, dev, dev_index, world, cam, cam_arr, wkey, 
             "exchange": None, "exchange_bytes_per_frame": 0,
             "rays_per_frame_primary_shadow": int(round(ps(st) / frames)),
             "rays_per_frame_other": int(round((st["rays_reflect"] + st["rays_refract"]) / frames)),
+            "primary_rays_per_frame_answered_by_the_tile_proof": int(round(st["rays_primary_proven_miss"] / frames)),
+            "tile_proof_note": "of the primary rays: those of 8-row tile bands the launch's binning kernel PROVED to hit nothing (empty candidate lists, cones clear "
+                               "of every plane: the sky) - counted, as the reference casts them, but no ray is generated (rtc_stats.rays_primary_proven_miss)",
         },
         "roofline": roof,
         "launch": info,
