@@ -424,8 +424,11 @@ rtc_status  rtc_host_unregister(void *p);
  * independent work item of the rayon pool). A group is N GPUs that render one frame together: member r
  * renders the 8-row bands r, r+N, r+2N, ... (rtc_render_bands), then ONE exchange step — an RCCL gather
  * of the f64 tiles to member 0 over xGMI (ncclGather) — and one un-deal kernel on member 0's device puts
- * the bands back in the reference's row-major Canvas (canvas.rs:43-51). The World (a few MB at most) is
- * replicated. Two ways to form a group:
+ * the bands back in the reference's row-major Canvas (canvas.rs:43-51). The World is
+ * replicated: its tables are 0.7 KB per object (7 MB for 10 000 objects), plus — per member — the light-space shadow
+ * lists of a World above 256 objects (~50 MB: 6 x 128^2 direction cells of 128 entries) and, allocated by the first binned
+ * launch, two sets of per-tile candidate lists (8.4 MB per 1080p view, up to 8 views per set while a set stays within 128 MB).
+ * Both kinds of lists are optimisations: when their allocation fails the launch renders through the walk instead. Two ways to form a group:
  *   rtc_group_create       one process drives all `ndev` devices (ncclCommInitAll) — what a Rust host
  *                          calling Camera::render_async would use;
  *   rtc_group_create_rank  one process per GPU (torchrun / MPI style): every process creates its member

@@ -556,18 +556,29 @@ rtc_status rtc_world_create(rtc_context *ctx, const rtc_shape *shapes, uint32_t 
             const uint32_t cap = n > 256 ? RTC_LIGHT_LIST_CAP : RTC_LIGHT_LIST_CAP_SMALL;
             w->light_cap = cap;
             const size_t cells = 6u * (size_t)RTC_LIGHT_R * RTC_LIGHT_R, macros = 6u * (size_t)(RTC_LIGHT_R / 8u) * (RTC_LIGHT_R / 8u);
-            ok = hipMalloc(&w->d_light_cells, sizeof(DevTileBundle) * (cells + macros)) == hipSuccess &&
-                 hipMalloc(&w->d_light_cnt, sizeof(uint32_t) * cells) == hipSuccess &&
-                 hipMalloc(&w->d_light_list, sizeof(uint32_t) * cells * cap) == hipSuccess &&
-                 rtc_launch_light_lists(n, cap, w->d_bound, light->position, reach, w->d_light_cells, w->d_light_cells + cells, w->d_light_cnt,
-                                        w->d_light_list, ctx->stream) == hipSuccess &&
-                 hipStreamSynchronize(ctx->stream) == hipSuccess;
-            w->light_reach = reach;
+            // the lists are an optimisation (the shadow pass walks without them): a failed allocation must not fail the upload
+            const bool got = hipMalloc(&w->d_light_cells, sizeof(DevTileBundle) * (cells + macros)) == hipSuccess &&
+                             hipMalloc(&w->d_light_cnt, sizeof(uint32_t) * cells) == hipSuccess &&
+                             hipMalloc(&w->d_light_list, sizeof(uint32_t) * cells * cap) == hipSuccess;
+            if (got) {
+                ok = rtc_launch_light_lists(n, cap, w->d_bound, light->position, reach, w->d_light_cells, w->d_light_cells + cells, w->d_light_cnt,
+                                            w->d_light_list, ctx->stream) == hipSuccess &&
+                     hipStreamSynchronize(ctx->stream) == hipSuccess;
+                w->light_reach = reach;
+            } else {
+                (void)hipGetLastError();
+                if (w->d_light_cells) (void)hipFree(w->d_light_cells);
+                if (w->d_light_cnt) (void)hipFree(w->d_light_cnt);
+                if (w->d_light_list) (void)hipFree(w->d_light_list);
+                w->d_light_cells = nullptr; w->d_light_cnt = nullptr; w->d_light_list = nullptr;
+                w->light_cap = 0;
+            }
         }
     }
     if (!ok) {
+        const hipError_t e = hipGetLastError();
         rtc_world_destroy(w);
-        return RTC_ERR_DEVICE;
+        return e == hipErrorOutOfMemory ? RTC_ERR_NOMEM : RTC_ERR_DEVICE;
     }
     *out = w;
     return RTC_OK;
