@@ -598,17 +598,22 @@ DEVI float bound_key(V3 apex, const DevBound &b) {
 
 // Direction (from the light) -> cube-map cell. Face = the axis of the largest component (ties: x before y before z) and
 // its sign; (u, v) = the other two components over it, each in [-1, 1]; cell = floor((u + 1) * R / 2), clamped.
+// Evaluated in f32 (a third of the f64 form's instructions, one of them a division): the direction is unit, so u/m and v/m carry
+// an absolute error below 3e-7 — 2e-5 of a cell — which k_light_cells' cones cover fifty times over (their half-angles are
+// widened by 1e-5 rad for exactly this: a direction on a cell border may land in either cell); a tie between two components
+// resolved differently than in f64 is a direction on a face border, covered by both faces' border cells the same way.
 DEVI uint32_t light_cell(V3 d) {
-    const double ax = fabs(d.x), ay = fabs(d.y), az = fabs(d.z);
+    const float x = (float)d.x, y = (float)d.y, z = (float)d.z;
+    const float ax = fabsf(x), ay = fabsf(y), az = fabsf(z);
     uint32_t a;
-    double m, u, v;
-    if (ax >= ay && ax >= az) { a = 0u; m = d.x; u = d.y; v = d.z; }
-    else if (ay >= az) { a = 1u; m = d.y; u = d.z; v = d.x; }
-    else { a = 2u; m = d.z; u = d.x; v = d.y; }
-    const double im = 1.0 / fabs(m);
-    const double fu = (u * im + 1.0) * (0.5 * RTC_LIGHT_R), fv = (v * im + 1.0) * (0.5 * RTC_LIGHT_R);
-    const int iu = (int)fmin(fmax(fu, 0.0), (double)(RTC_LIGHT_R - 1u)), iv = (int)fmin(fmax(fv, 0.0), (double)(RTC_LIGHT_R - 1u)); // NaN -> 0
-    return ((a * 2u + (m < 0. ? 1u : 0u)) * RTC_LIGHT_R + (uint32_t)iv) * RTC_LIGHT_R + (uint32_t)iu;
+    float m, u, v;
+    if (ax >= ay && ax >= az) { a = 0u; m = x; u = y; v = z; }
+    else if (ay >= az) { a = 1u; m = y; u = z; v = x; }
+    else { a = 2u; m = z; u = x; v = y; }
+    const float im = __builtin_amdgcn_rcpf(fabsf(m));
+    const float fu = (u * im + 1.0f) * (0.5f * RTC_LIGHT_R), fv = (v * im + 1.0f) * (0.5f * RTC_LIGHT_R);
+    const int iu = (int)fminf(fmaxf(fu, 0.0f), (float)(RTC_LIGHT_R - 1u)), iv = (int)fminf(fmaxf(fv, 0.0f), (float)(RTC_LIGHT_R - 1u)); // NaN -> 0
+    return ((a * 2u + (m < 0.f ? 1u : 0u)) * RTC_LIGHT_R + (uint32_t)iv) * RTC_LIGHT_R + (uint32_t)iu;
 }
 // Per-lane prefilter for INCOHERENT rays (reflection / refraction): can THIS lane's ray, for some
 // t >= 0, touch the object's bounding sphere? false => the exact test would find no entry with
