@@ -1656,21 +1656,25 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                 const auto &Pl = KP(P_arg);
                 if (Pl.light_cnt != nullptr && !Bs.off && Bs.tmax <= Pl.light_reach && ballot(hit) != 0ull) {
                     const uint32_t cid = hit ? light_cell(vneg(sdir)) : 0u;
-                    listed = true;
-                    for (unsigned long long todo = ballot(hit); todo;) { // a cell whose list overflowed is incomplete: walk instead
-                        const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cid, (int)__builtin_ctzll(todo));
-                        todo &= ~ballot(hit && cid == c);
-                        if (Pl.light_cnt[c] > Pl.light_cap) { listed = false; break; }
-                    }
+                    const uint32_t ccnt = hit ? Pl.light_cnt[cid] : 0u;          // every lane its own cell's counter: one round trip
+                    listed = ballot(hit && ccnt > Pl.light_cap) == 0ull;       // a cell whose list overflowed is incomplete: walk instead
                     if (listed) {
                         for (uint32_t k = 0; k < Pl.n_unb && ballot(sh_pending) != 0ull; ++k) { // unbounded objects: never listed
                             DIAG(5, 1u);
                             if (sh_pending && occludes_world(T.kind_s[k], T.isect_s[k].m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
                         }
+                        bool pre_ok; // pre-inflated prefilter records hold while every origin is within their limit (DevPre)
+                        double sdd;
+                        {
+#pragma clang fp contract(fast)
+                            pre_ok = ballot(hit && !(fabs(over.x) + fabs(over.y) + fabs(over.z) <= Pl.pre_limit)) == 0ull;
+                            sdd = sdir.x * sdir.x + sdir.y * sdir.y + sdir.z * sdir.z;
+                        }
                         for (unsigned long long todo = ballot(hit); todo && ballot(sh_pending) != 0ull;) {
-                            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cid, (int)__builtin_ctzll(todo));
+                            const int cl = (int)__builtin_ctzll(todo);
+                            const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)cid, cl);
+                            const uint32_t nl = (uint32_t)__builtin_amdgcn_readlane((int)ccnt, cl);
                             todo &= ~ballot(hit && cid == c);
-                            const uint32_t nl = Pl.light_cnt[c];
                             const uint32_t *ll = Pl.light_list + (size_t)c * Pl.light_cap;
                             for (uint32_t base = 0; base < nl && ballot(sh_pending) != 0ull; base += 64u) {
                                 const uint32_t e = base + lane;
@@ -1679,14 +1683,35 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                                 if (e < nl) { idx = ll[e]; cand = bundle_touches(Bs, T.bound[idx]); }
                                 DIAG_FILTER(DIAG_PTR(9));
                                 unsigned long long mask = ballot(cand);
-                                while (mask) {
-                                    const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)idx, (int)__builtin_ctzll(mask));
+                                while (mask && ballot(sh_pending) != 0ull) { // survivors two at a time (RTC_PRE_BATCH, as for_each_object)
+                                    const uint32_t j0 = (uint32_t)__builtin_amdgcn_readlane((int)idx, (int)__builtin_ctzll(mask));
                                     mask &= mask - 1ull;
+                                    uint32_t j1 = j0;
+                                    const bool two = mask != 0ull;
+                                    if (two) { j1 = (uint32_t)__builtin_amdgcn_readlane((int)idx, (int)__builtin_ctzll(mask)); mask &= mask - 1ull; }
                                     DIAG_FILTER(DIAG_PTR(11));
-                                    if (ballot(sh_pending && ray_touches(over, sdir, T.bound[j])) == 0ull) continue;
-                                    DIAG(5, 1u);
-                                    if (sh_pending && occludes_world(T.kind[j], T.isect[j].m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
-                                    if (ballot(sh_pending) == 0ull) break;
+                                    unsigned long long b0, b1;
+                                    if (pre_ok) {
+                                        const DevPre q0 = T.pre[j0], q1 = T.pre[j1];
+                                        const bool t0 = ray_touches_pre(over, sdir, sdd, q0), t1 = ray_touches_pre(over, sdir, sdd, q1);
+                                        b0 = ballot(sh_pending & t0);
+                                        b1 = two ? ballot(sh_pending & t1) : 0ull;
+                                    } else {
+                                        b0 = ballot(sh_pending && ray_touches(over, sdir, T.bound[j0]));
+                                        b1 = two ? ballot(sh_pending && ray_touches(over, sdir, T.bound[j1])) : 0ull;
+                                    }
+                                    if (b0 != 0ull) {
+                                        DIAG(5, 1u);
+                                        const DevIsect rec = T.isect[j0];
+                                        const uint32_t kd = T.kind[j0];
+                                        if (sh_pending && occludes_world(kd, rec.m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
+                                    }
+                                    if (b1 != 0ull && ballot(sh_pending) != 0ull) {
+                                        DIAG(5, 1u);
+                                        const DevIsect rec = T.isect[j1];
+                                        const uint32_t kd = T.kind[j1];
+                                        if (sh_pending && occludes_world(kd, rec.m, over, sdir, sdist)) { shadowed = true; sh_pending = false; }
+                                    }
                                 }
                             }
                         }
