@@ -75,6 +75,12 @@
 #ifndef RTC_SHADOW_LANE_FILTER
 #define RTC_SHADOW_LANE_FILTER(SRC, REFL) ((SRC) == SRC_CULL2 || (REFL))
 #endif
+// Apex of a secondary bundle: 0 = centroid of the origins (tighter origin spread), 1 = the axis lane's origin (four wave
+// reductions less per secondary pass: C4 -1.4 %, reflective 1080p -1 %; profiles/r03_exp_small_steps.log). Either is conservative: rho is
+// measured from whatever apex is chosen.
+#ifndef RTC_BUNDLE_APEX_LANE
+#define RTC_BUNDLE_APEX_LANE 1
+#endif
 #ifndef RTC_PRIMARY_LANE_FILTER
 #define RTC_PRIMARY_LANE_FILTER(SRC) false
 #endif
@@ -493,10 +499,17 @@ DEVI Bundle make_bundle(bool active, V3 apex, V3 o, V3 d, double reach) {
     if (!narrow) cmin = 1.f - wave_max_nonneg(good ? fmaxf(0.f, 1.f - dotv) : 0.f);
     float rho = 0.f;
     if constexpr (!SHARED) {
+#if RTC_BUNDLE_APEX_LANE
+        // apex = the origin of the axis lane (three readlanes) instead of the centroid of the origins (four wave sums)
+        const float mx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (float)o.x), lane0));
+        const float my = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (float)o.y), lane0));
+        const float mz = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, (float)o.z), lane0));
+#else
         const float cnt = fmaxf(wave_sum(good ? 1.f : 0.f), 1.f);
         const float mx = wave_sum(good ? (float)o.x : 0.f) / cnt;
         const float my = wave_sum(good ? (float)o.y : 0.f) / cnt;
         const float mz = wave_sum(good ? (float)o.z : 0.f) / cnt;
+#endif
         apex = mk((double)mx, (double)my, (double)mz);
         float e2 = 0.f;
         if (good) {
