@@ -779,7 +779,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
                             uint32_t cnt = 0;
 #pragma unroll
                             for (uint32_t k = 0; k < RTC_PRE_BATCH; ++k) {
-                                jx[k] = jx[0];
+                                jx[k] = k ? jx[0] : base + sl * 64u; // (slots past the last candidate repeat the first: a harmless second look)
                                 if (mask) {
                                     jx[k] = base + sl * 64u + (uint32_t)__builtin_ctzll(mask);
                                     mask &= mask - 1ull;
