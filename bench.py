@@ -283,7 +283,9 @@ def run_single(args, rtc, np, torch, dev, dev_index, world, cam, cam_arr, wkey, 
             dworld.render_rows(cam, 0, H, ptrs[i % R], rtc.MODE_RENDER_ASYNC)
         else:
             dworld.render_views(cam_arr[V], 0, 1, ptrs[i % R], HP, rtc.MODE_RENDER_ASYNC)
-    sync = ctx.synchronize
+    def sync():   # the context's lanes and stream, then the device (the driver's contract: torch.cuda.synchronize() on both sides)
+        ctx.synchronize()
+        torch.cuda.synchronize(dev)
 
     def solo_leg(n):
         """n launches, a synchronize after each: every kernel has the GPU to itself (its own binning kernel in front of it on the
@@ -471,7 +473,9 @@ def run_group(args, rtc, np, torch, dist, dev, dev_index, world, cam, cam_arr, w
         state["batch"] += 1
         gworld.render(cam_arr[state["v"]], state["what"], canv[b].data_ptr() if rank == 0 else None,
                       canv8[b].data_ptr() if rank == 0 else None)
-    sync = group.synchronize
+    def sync():   # every member stream of this rank, then the device
+        group.synchronize()
+        torch.cuda.synchronize(dev)
     stats, reset_stats = group.stats, group.reset_stats
 
     for _ in range(4):     # first-use costs (code object load, communicator set-up, tile buffers) never land in a timed region
