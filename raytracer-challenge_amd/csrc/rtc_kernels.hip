@@ -2267,17 +2267,29 @@ __global__ void __launch_bounds__(64) k_bin_tiles(const BinParams Q, const DevBo
     for (uint32_t gbase = 0; gbase < ngroups; gbase += 64u) {
         const uint32_t g = gbase + lane;
         unsigned long long gmask = ballot(g < ngroups && bundle_touches(MB, gbound[g])); // (a group with an unbounded member: r = inf, kept)
+        // the members' bounds of the NEXT touched group are requested before the current group's survivors are appended: the
+        // expansions are a chain of dependent 48-byte-per-lane gathers otherwise (C3: 92 -> see profiles/r03_exp_small_steps.log)
+        const DevBound none = DevBound{0., 0., 0., __builtin_inf(), 0., 0.};
+        auto fetch = [&](uint32_t gs, DevBound &bb, uint32_t &oo) {
+            const uint32_t kk = gs * 64u + lane;
+            bb = none; oo = 0u;
+            if (kk < Q.n) { bb = bound_s[kk]; oo = orig_s[kk]; }
+        };
+        DevBound b_next = none;
+        uint32_t o_next = 0u;
+        if (gmask) fetch(gbase + (uint32_t)__builtin_ctzll(gmask), b_next, o_next);
         while (gmask) {
             const uint32_t gsel = gbase + (uint32_t)__builtin_ctzll(gmask);
             gmask &= gmask - 1ull;
+            const DevBound b = b_next;
+            const uint32_t orig = o_next;
+            if (gmask) fetch(gbase + (uint32_t)__builtin_ctzll(gmask), b_next, o_next);
             const uint32_t k = gsel * 64u + lane;
             bool to = false;
-            DevBound b = DevBound{0., 0., 0., __builtin_inf(), 0., 0.};
             uint32_t entry = 0u;
             if (k < Q.n) {
-                b = bound_s[k];
                 to = b.r < __builtin_inf() && bundle_touches(MB, b); // unbounded objects are never listed: every tile tests them anyway
-                if (to) entry = bin_entry(Q, o, b, orig_s[k]);
+                if (to) entry = bin_entry(Q, o, b, orig);
             }
             unsigned long long omask = ballot(to);
             while (omask) { // the survivor's record comes from the lane that tested it (readlane: no second round trip to memory)
