@@ -2320,8 +2320,11 @@ __global__ void __launch_bounds__(64) k_bin_tiles(const BinParams Q, const DevBo
     const uint32_t rmin = ~wave_max_u32(nonempty ? ~ty : 0u), rmaxinv = ~wave_max_u32(nonempty ? ty : 0u);
     const bool any_nonempty = ballot(nonempty) != 0ull; // (evaluated by the whole wave, not under the lane-0 branch)
     if (lane == 0u && any_nonempty) {
-        atomicMin(rows + 2u * view, rmin);
-        atomicMin(rows + 2u * view + 1u, rmaxinv);
+        // look before the atomic: the words only ever decrease, so a (possibly stale) value that is already small enough makes it
+        // redundant — at 8192^2 sixteen thousand waves would otherwise queue on these two words (C5: the binning kernel 0.38 ms)
+        volatile uint32_t *rw = rows + 2u * view;
+        if (rmin < rw[0]) atomicMin(rows + 2u * view, rmin);
+        if (rmaxinv < rw[1]) atomicMin(rows + 2u * view + 1u, rmaxinv);
     }
 }
 
