@@ -2264,6 +2264,11 @@ __global__ void __launch_bounds__(64) k_bin_tiles(const BinParams Q, const DevBo
     const size_t tile = (size_t)(view * Q.tiles_y + min(ty, Q.tiles_y - 1u)) * Q.tiles_x + min(tx, Q.tiles_x - 1u);
     uint32_t *my_list = list + tile * RTC_TILE_LIST_CAP;
     uint32_t my_cnt = 0;
+    // is this tile's cone clear of every unbounded object? (uniform loop, scalar loads, ahead of the group walk so that their latency
+    // is not on the kernel's tail; used below for the tile-row proof)
+    bool clear_of_planes = n_unb <= 4u;
+    for (uint32_t k = 0; k < n_unb && n_unb <= 4u; ++k)
+        clear_of_planes = clear_of_planes && (kind_s[k] == RTC_PLANE) && cone_misses_plane(isect_s[k].m, o, tcone);
     for (uint32_t gbase = 0; gbase < ngroups; gbase += 64u) {
         const uint32_t g = gbase + lane;
         unsigned long long gmask = ballot(g < ngroups && bundle_touches(MB, gbound[g])); // (a group with an unbounded member: r = inf, kept)
@@ -2310,13 +2315,7 @@ __global__ void __launch_bounds__(64) k_bin_tiles(const BinParams Q, const DevBo
     // background_color there (shape.rs:702-710, 652-653) whatever the rays' exact directions. rows[2v] = the smallest,
     // ~rows[2v + 1] the largest tile row with a tile that is NOT proven empty (both preset to 0xffffffff): the render kernel
     // skips ray generation and every pass for the tile rows outside that range (the sky of a floor scene: a third of the north star).
-    bool nonempty = mine;
-    if (mine && my_cnt == 0u && n_unb <= 4u) {
-        bool proven = true;
-        for (uint32_t k = 0; k < n_unb && proven; ++k)
-            proven = kind_s[k] == RTC_PLANE && cone_misses_plane(isect_s[k].m, o, tcone);
-        nonempty = !proven;
-    }
+    const bool nonempty = mine && !(my_cnt == 0u && clear_of_planes);
     const uint32_t rmin = ~wave_max_u32(nonempty ? ~ty : 0u), rmaxinv = ~wave_max_u32(nonempty ? ty : 0u);
     const bool any_nonempty = ballot(nonempty) != 0ull; // (evaluated by the whole wave, not under the lane-0 branch)
     if (lane == 0u && any_nonempty) {
