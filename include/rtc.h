@@ -254,17 +254,49 @@ rtc_status  rtc_scene_load_yaml(const char *text, rtc_shape **shapes_out, uint32
 rtc_status  rtc_scene_load_yaml_file(const char *path, rtc_shape **shapes_out, uint32_t *n_out,
                                      rtc_light *light_out, rtc_camera *camera_out,
                                      char *errbuf, size_t errbuf_len);
-/* Scene loader for the TABLE-LITERAL subset of the reference's Lua front-end (ch1/src/lua.rs:57-79,109-330; scenes like
- * ch1/jamis.lua:1-56): global assignments of table constructors, constant arithmetic (math.pi), and
- * `Render(world, camera, "file")` calls. The tables are turned into World and Camera by lua.rs's own rules —
- * transform_from_table's fixed order rotate_x, rotate_y, rotate_z, scale, position; materials from Material::default()
- * with the keys ambient, diffuse, specular, shininess, reflectiveness, transparency, refractive_index, color, pattern
- * (anything else is an error) and the shape-level color / pattern override; patterns "checks" / "stripes" / "grid";
- * lights[1] only; camera screenwidth / screenheight / samples as Lua integers. `render_index` selects the k-th Render
- * call of the script (0 = the first; a script without any falls back to its globals `world` and `camera`);
- * *renders_out (may be NULL) = how many the script makes; `outfile` (may be NULL) receives that call's file name.
- * Anything that needs an interpreter — functions, loops, require, calls other than Render — is RTC_ERR_PARSE with a
- * message saying so (ex2.lua, functions.lua). PARITY UNPINNED: the reference has no test of its Lua path. [host] */
+/* The reference's Lua front-end (ch1/src/lua.rs:50-330; scripts ch1/jamis.lua, ex1.lua, ex2.lua + functions.lua) without a
+ * Lua library: csrc/host_lua.cpp interprets the part of Lua 5.3 those scripts are written in (functions and closures,
+ * numeric / generic for, while, repeat, if, multiple assignment, tables, integer / float numbers, strings; print, require of
+ * files beside the script, math.*, string.format, table.insert ...; no metatables, coroutines, goto or bitwise operators)
+ * and gives a script the reference's three entry points:
+ *   Render(world, camera, outfile)                              lua.rs:57-71
+ *   enc = StartAnimation(outfile); enc:AddFrame(world, camera); enc:Finish()     lua.rs:34-45,75-79
+ * Every Render / AddFrame call converts its tables AT THE CALL by lua.rs's own rules — transform_from_table's fixed order
+ * rotate_x, rotate_y, rotate_z, scale, position; materials from Material::default() with the keys ambient, diffuse,
+ * specular, shininess, reflectiveness, transparency, refractive_index, color, pattern (anything else is an error) and the
+ * shape-level color / pattern override; patterns "checks" / "stripes" / "grid"; lights[1] only; camera screenwidth /
+ * screenheight / samples as Lua integers — and becomes one JOB: a world, a camera, the output file's name. The caller renders
+ * the jobs in order (one rtc_render* launch each: an AddFrame loop is the one-camera-per-launch sequence a pipelined
+ * context overlaps); encoding GIF / PNG / JPEG files is the `image` crate's business in the reference and nobody's here.
+ * math.random is Lua 5.3's on POSIX (glibc random(), restated), so `math.randomseed(13)` worlds are reproducible.
+ * A script runs under a step budget (`step_limit` statements / loop iterations / calls, 0 = 100 000 000) and cannot touch
+ * the file system except through require (`base_dir`/name.lua; NULL = require is an error). Syntax and runtime errors,
+ * and tables lua.rs would reject, are RTC_ERR_PARSE with the message in errbuf (the reference unwrap()s: it panics).
+ * PARITY UNPINNED: the reference has no test of its Lua path. [host] */
+typedef struct rtc_lua_program rtc_lua_program;
+enum { RTC_LUA_JOB_RENDER = 0, RTC_LUA_JOB_ADD_FRAME = 1 };
+typedef struct rtc_lua_job {
+    const rtc_shape *shapes;          /* owned by the program; NULL when the world is empty                            */
+    uint32_t         n_shapes;
+    uint32_t         kind;            /* RTC_LUA_JOB_RENDER | RTC_LUA_JOB_ADD_FRAME                                    */
+    rtc_light        light;
+    rtc_camera       camera;
+    const char      *outfile;         /* Render's third argument / the animation's file name; owned by the program     */
+    uint32_t         animation;       /* AddFrame: which StartAnimation call (0, 1, ...) the encoder came from         */
+    uint32_t         frame;           /* AddFrame: index of the frame inside that animation                            */
+    uint32_t         same_world_as_previous; /* 1: shapes and light equal the previous job's byte for byte (same arrays) */
+    uint32_t         line;            /* script line of the call                                                      */
+} rtc_lua_job;
+rtc_status  rtc_lua_run(const char *text, const char *base_dir, uint64_t step_limit, rtc_lua_program **out,
+                        char *errbuf, size_t errbuf_len);
+rtc_status  rtc_lua_run_file(const char *path, uint64_t step_limit, rtc_lua_program **out, char *errbuf, size_t errbuf_len);
+uint32_t    rtc_lua_program_jobs(const rtc_lua_program *prog);
+rtc_status  rtc_lua_program_job(const rtc_lua_program *prog, uint32_t index, rtc_lua_job *job);
+const char *rtc_lua_program_output(const rtc_lua_program *prog);   /* everything the script print()ed */
+void        rtc_lua_program_free(rtc_lua_program *prog);
+/* The single-scene form: runs the script as above and hands out job `render_index` (0 = the first Render / AddFrame call;
+ * a script that makes none falls back to its globals `world` and `camera`) as a malloc'ed shape array (rtc_free);
+ * *renders_out (may be NULL) = how many jobs the script made; `outfile` (may be NULL) receives that job's file name. */
 rtc_status  rtc_scene_load_lua(const char *text, uint32_t render_index, rtc_shape **shapes_out, uint32_t *n_out,
                                rtc_light *light_out, rtc_camera *camera_out, char *outfile, size_t outfile_len,
                                uint32_t *renders_out, char *errbuf, size_t errbuf_len);
@@ -355,6 +387,16 @@ rtc_status  rtc_render(rtc_context *ctx, const rtc_world *w, const rtc_camera *c
  * canvas is not even written to HBM. Feed it to rtc_canvas_write_ppm_rgb8. Synchronous. `stats` may be NULL. */
 rtc_status  rtc_render_rgb8(rtc_context *ctx, const rtc_world *w, const rtc_camera *cam,
                             uint32_t mode, uint32_t flags, uint8_t *rgb8, rtc_stats *stats);
+/* render_lua (lua.rs:50-91) for an interpreted script: renders every job of `prog` in order — one launch per Render /
+ * AddFrame call, 8-bit rows only (what the reference's file writers consume), a new device World whenever a job's world
+ * differs from the previous one — and hands each frame (vsize*hsize*3 bytes, Color::scale, valid during the call only) to
+ * `fn` in job order. The launches are pipelined over the context's lanes (depth 3 for the duration when the context is in
+ * order) with each frame's copy to the host on its own lane: an AddFrame loop is the one-camera-per-launch sequence of
+ * Camera::render_async calls. A non-zero return from `fn` stops the rendering (RTC_OK). `stats` (may be NULL) = the ray
+ * counts of all frames. Blocking. [device] */
+typedef int (*rtc_lua_frame_fn)(void *user, const rtc_lua_job *job, uint32_t job_index, const uint8_t *rgb8);
+rtc_status  rtc_lua_program_render(rtc_context *ctx, const rtc_lua_program *prog, uint32_t mode, uint32_t flags,
+                                   rtc_lua_frame_fn fn, void *user, rtc_stats *stats);
 /* Page-locked host memory for canvases handed to rtc_render: a canvas from rtc_host_alloc is
  * filled by one DMA at link speed, ordinary (pageable) memory goes through the runtime's bounce
  * buffers and is several times slower. What the reference would use for Canvas.pixels

@@ -17,7 +17,7 @@ from pathlib import Path
 
 import numpy as np
 
-from .abi import (RtcCamera, RtcHit, RtcLaunchInfo, RtcLight, RtcMaterial, RtcShape, RtcStats, Mat16, Vec3, SOURCE_NAMES,
+from .abi import (LUA_FRAME_FN, RtcLuaJob, RtcCamera, RtcHit, RtcLaunchInfo, RtcLight, RtcMaterial, RtcShape, RtcStats, Mat16, Vec3, SOURCE_NAMES,
                   SPHERE, PLANE, CUBE, MODE_RENDER, MODE_RENDER_ASYNC, FLAG_NONE, FLAG_NO_CULL, FLAG_AA_RESAMPLE, FLAG_LDS_TABLE,
                   EXCHANGE_RCCL, EXCHANGE_P2P, GATHER_NONE, GATHER_F64, GATHER_U8, GROUP_ID_BYTES, PATTERNS, STATUS_NAMES, declare)
 
@@ -248,8 +248,98 @@ def load_yaml(text: str | None = None, path: str | None = None):
     return w, cam
 
 
+class LuaJob:
+    """One Render(world, camera, file) or encoder:AddFrame(world, camera) call of a script (rtc_lua_job), converted by
+    lua.rs's *_from_table rules at the moment of the call."""
+
+    def __init__(self, j: RtcLuaJob, index: int):
+        self.index = index
+        self.kind = "AddFrame" if j.kind == 1 else "Render"
+        self.outfile = (j.outfile or b"").decode(errors="replace")
+        self.animation, self.frame, self.line = j.animation, j.frame, j.line
+        self.same_world_as_previous = bool(j.same_world_as_previous)
+        self.camera = RtcCamera()
+        C.memmove(C.byref(self.camera), C.byref(j.camera), C.sizeof(RtcCamera))
+        lgt = RtcLight()
+        C.memmove(C.byref(lgt), C.byref(j.light), C.sizeof(RtcLight))
+        self.world = World(lgt)
+        for i in range(j.n_shapes):
+            s = RtcShape()
+            C.memmove(C.byref(s), C.byref(j.shapes[i]), C.sizeof(RtcShape))
+            self.world.shapes.append(s)
+
+
+class LuaProgram:
+    """A scene script of the reference's Lua front-end, interpreted (rtc_lua_run: csrc/host_lua.cpp carries its own
+    interpreter of the Lua 5.3 subset those scripts use): `jobs` = its Render / AddFrame calls in order, `output` = what it
+    print()ed. render(ctx) is lua.rs's render_lua: every job rendered on the GPU, 8-bit frames back in job order."""
+
+    def __init__(self, text: str | None = None, path=None, base_dir=None, step_limit: int = 0):
+        h = C.c_void_p()
+        err = C.create_string_buffer(1024)
+        if path is not None:
+            st = lib().rtc_lua_run_file(str(path).encode(), step_limit, C.byref(h), err, 1024)
+        else:
+            st = lib().rtc_lua_run(text.encode(), None if base_dir is None else str(base_dir).encode(), step_limit, C.byref(h), err, 1024)
+        _check(st, "rtc_lua_run", err.value.decode(errors="replace"))
+        self._h = h
+        self.output = lib().rtc_lua_program_output(h).decode(errors="replace")
+
+    def __len__(self):
+        return lib().rtc_lua_program_jobs(self._h) if self._h else 0
+
+    def job(self, index: int) -> LuaJob:
+        j = RtcLuaJob()
+        _check(lib().rtc_lua_program_job(self._h, index, C.byref(j)), "rtc_lua_program_job")
+        return LuaJob(j, index)
+
+    @property
+    def jobs(self):
+        return [self.job(i) for i in range(len(self))]
+
+    def render(self, ctx: "Context", on_frame=None, mode: int = MODE_RENDER_ASYNC, flags: int = 0, with_stats: bool = False):
+        """rtc_lua_program_render: returns the list of (vsize, hsize, 3) uint8 frames in job order — or, with `on_frame`
+        (called as on_frame(job_index, frame, outfile, kind); a true return value stops), nothing is kept."""
+        frames = []
+        raised = []
+
+        def cb(_user, jp, index, rgb8):
+            try:
+                cam = jp.contents.camera
+                frame = np.ctypeslib.as_array(rgb8, shape=(cam.vsize, cam.hsize, 3))
+                if on_frame is None:
+                    frames.append(frame.copy())
+                    return 0
+                j = jp.contents
+                return 1 if on_frame(index, frame, (j.outfile or b"").decode(errors="replace"), "AddFrame" if j.kind == 1 else "Render") else 0
+            except BaseException as e:  # never unwind through the C frames
+                raised.append(e)
+                return 1
+
+        st = RtcStats()
+        fn = LUA_FRAME_FN(cb)
+        rc = lib().rtc_lua_program_render(ctx._h, self._h, mode, flags, fn, None, C.byref(st) if with_stats else None)
+        if raised:
+            raise raised[0]
+        _check(rc, "rtc_lua_program_render")
+        if with_stats:
+            return frames, _stats_dict(st, True)
+        return frames
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rtc_lua_program_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def load_lua(text: str | None = None, path: str | None = None, render_index: int = 0):
-    """Table-literal subset of the reference's Lua scenes (rtc_scene_load_lua) -> (World, RtcCamera, outfile, n_render_calls)."""
+    """One job of a Lua scene script (rtc_scene_load_lua) -> (World, RtcCamera, outfile, n_jobs)."""
     shapes = C.POINTER(RtcShape)()
     n, renders = C.c_uint32(0), C.c_uint32(0)
     lgt, cam = RtcLight(), RtcCamera()
@@ -714,7 +804,7 @@ def group_undeal_host(staging: np.ndarray, nranks: int, nframes: int, vsize: int
 
 
 __all__ = ["lib", "RtcError", "Matrix", "material", "sphere", "plane", "cube", "light", "World", "camera", "ray_for_pixel",
-           "load_yaml", "load_lua", "format_ppm", "write_ppm", "color_scale255", "Context", "DeviceWorld", "MODE_RENDER", "MODE_RENDER_ASYNC", "FLAG_NONE", "FLAG_NO_CULL", "FLAG_AA_RESAMPLE", "Group", "GroupWorld", "group_unique_id",
+           "load_yaml", "load_lua", "LuaProgram", "LuaJob", "format_ppm", "write_ppm", "color_scale255", "Context", "DeviceWorld", "MODE_RENDER", "MODE_RENDER_ASYNC", "FLAG_NONE", "FLAG_NO_CULL", "FLAG_AA_RESAMPLE", "Group", "GroupWorld", "group_unique_id",
            "host_register", "host_unregister", "host_canvas", "host_canvas_rgb8", "format_ppm_rgb8", "write_ppm_rgb8",
            "group_packed_rows", "group_bands_owned", "group_row_owner", "group_packed_row_to_image", "group_undeal_host", "EXCHANGE_RCCL", "EXCHANGE_P2P", "GATHER_NONE", "GATHER_F64", "GATHER_U8",
            "SPHERE", "PLANE", "CUBE", "RtcCamera", "RtcHit", "RtcLight", "RtcMaterial", "RtcShape", "RtcStats"]

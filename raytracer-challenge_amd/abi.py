@@ -56,6 +56,14 @@ class RtcLaunchInfo(C.Structure):
                 ("tiles_per_workgroup", C.c_uint32), ("_reserved", C.c_uint32 * 3)]
 
 
+class RtcLuaJob(C.Structure):
+    _fields_ = [("shapes", C.POINTER(RtcShape)), ("n_shapes", C.c_uint32), ("kind", C.c_uint32), ("light", RtcLight), ("camera", RtcCamera),
+                ("outfile", C.c_char_p), ("animation", C.c_uint32), ("frame", C.c_uint32), ("same_world_as_previous", C.c_uint32),
+                ("line", C.c_uint32)]
+
+
+LUA_FRAME_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(RtcLuaJob), C.c_uint32, C.POINTER(C.c_uint8))
+
 SOURCE_NAMES = {0: "brute force, records through the scalar cache", 1: "brute force, object table staged in LDS (one tile)",
                 2: "brute force, object table staged in LDS tiles", 3: "one-level per-wave cull", 4: "two-level per-wave cull"}
 
@@ -92,6 +100,13 @@ PROTOTYPES = {
                                         C.POINTER(RtcCamera), C.c_char_p, C.c_size_t]),
     "rtc_scene_load_yaml_file": (C.c_int32, [C.c_char_p, C.POINTER(C.POINTER(RtcShape)), C.POINTER(U32), C.POINTER(RtcLight),
                                              C.POINTER(RtcCamera), C.c_char_p, C.c_size_t]),
+    "rtc_lua_run": (C.c_int32, [C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "rtc_lua_run_file": (C.c_int32, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
+    "rtc_lua_program_jobs": (C.c_uint32, [C.c_void_p]),
+    "rtc_lua_program_job": (C.c_int32, [C.c_void_p, C.c_uint32, C.POINTER(RtcLuaJob)]),
+    "rtc_lua_program_output": (C.c_char_p, [C.c_void_p]),
+    "rtc_lua_program_free": (None, [C.c_void_p]),
+    "rtc_lua_program_render": (C.c_int32, [C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, LUA_FRAME_FN, C.c_void_p, C.POINTER(RtcStats)]),
     "rtc_scene_load_lua": (C.c_int32, [C.c_char_p, U32, C.POINTER(C.POINTER(RtcShape)), C.POINTER(U32), C.POINTER(RtcLight),
                                        C.POINTER(RtcCamera), C.c_char_p, C.c_size_t, C.POINTER(U32), C.c_char_p, C.c_size_t]),
     "rtc_scene_load_lua_file": (C.c_int32, [C.c_char_p, U32, C.POINTER(C.POINTER(RtcShape)), C.POINTER(U32), C.POINTER(RtcLight),

@@ -1015,6 +1015,104 @@ rtc_status rtc_render_rgb8(rtc_context *ctx, const rtc_world *w, const rtc_camer
     return st;
 }
 
+// render_lua (lua.rs:50-91) for a program rtc_lua_run has interpreted: every job is one render launch, 8-bit rows only. The
+// launches go through the context's lanes (pipeline depth 3 unless the caller chose one), each followed on its own lane by
+// the copy of its frame into a page-locked host buffer — the shape of the reference's AddFrame loop, one camera per call —
+// and the frames are handed to `fn` in job order while later ones are still being rendered.
+rtc_status rtc_lua_program_render(rtc_context *ctx, const rtc_lua_program *prog, uint32_t mode, uint32_t flags, rtc_lua_frame_fn fn,
+                                  void *user, rtc_stats *stats) {
+    if (!ctx || !prog || mode > RTC_MODE_RENDER_ASYNC) return RTC_ERR_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    constexpr uint32_t RING = rtc_context::MAX_LANES + 1u; // a frame's buffers are reused only after `depth` later launches
+    struct Slot {
+        unsigned char *d = nullptr, *h = nullptr;
+        size_t cap = 0;
+        hipEvent_t done = nullptr;
+        bool pending = false;
+        uint32_t job = 0;
+    } ring[RING];
+    const uint32_t njobs = rtc_lua_program_jobs(prog);
+    const uint32_t lanes_before = ctx->lanes;
+    rtc_world *world = nullptr;
+    rtc_status st = RTC_OK;
+    bool stop = false;
+    auto deliver = [&](Slot &sl) -> rtc_status { // wait for the slot's frame and hand it over
+        if (!sl.pending) return RTC_OK;
+        sl.pending = false;
+        if (hipEventSynchronize(sl.done) != hipSuccess) return RTC_ERR_DEVICE;
+        rtc_lua_job job;
+        const rtc_status js = rtc_lua_program_job(prog, sl.job, &job);
+        if (js != RTC_OK) return js;
+        if (fn && !stop && fn(user, &job, sl.job, sl.h) != 0) stop = true;
+        return RTC_OK;
+    };
+    auto drain = [&](uint32_t next_job) -> rtc_status { // every frame in flight, oldest first
+        rtc_status r = RTC_OK;
+        for (uint32_t k = 0; k < RING; ++k) {
+            const rtc_status d = deliver(ring[(next_job + k) % RING]);
+            if (r == RTC_OK) r = d;
+        }
+        return r;
+    };
+    if (stats) st = rtc_stats_reset(ctx);
+    if (st == RTC_OK && lanes_before == 1u && njobs > 1u) st = rtc_context_set_pipeline(ctx, 3u);
+    uint32_t i = 0;
+    for (; st == RTC_OK && !stop && i < njobs; ++i) {
+        rtc_lua_job job;
+        st = rtc_lua_program_job(prog, i, &job);
+        if (st != RTC_OK) break;
+        const size_t bytes = (size_t)3 * job.camera.hsize * job.camera.vsize;
+        if (bytes == 0) { st = RTC_ERR_ARG; break; }
+        Slot &sl = ring[i % RING];
+        st = deliver(sl);
+        if (st != RTC_OK || stop) break;
+        if (!world || !job.same_world_as_previous) { // a new World: nothing may still read the old one
+            st = drain(i);
+            if (st == RTC_OK) st = rtc_context_synchronize(ctx);
+            if (st != RTC_OK || stop) break;
+            if (world) rtc_world_destroy(world);
+            world = nullptr;
+            st = rtc_world_create(ctx, job.shapes, job.n_shapes, &job.light, &world);
+            if (st != RTC_OK) break;
+        }
+        if (sl.cap < bytes) {
+            if (sl.d) (void)hipFree(sl.d);
+            if (sl.h) (void)hipHostFree(sl.h);
+            sl.d = sl.h = nullptr;
+            sl.cap = 0;
+            hipError_t e = hipMalloc(&sl.d, bytes);
+            if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void **>(&sl.h), bytes, hipHostMallocDefault);
+            if (e != hipSuccess) { (void)hipGetLastError(); st = e == hipErrorOutOfMemory ? RTC_ERR_NOMEM : RTC_ERR_DEVICE; break; }
+            sl.cap = bytes;
+        }
+        if (!sl.done && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) { st = RTC_ERR_DEVICE; break; }
+        st = rtc_render_rows(ctx, world, &job.camera, mode, 0, job.camera.vsize, nullptr, sl.d, flags);
+        if (st != RTC_OK) break;
+        hipStream_t s = ctx->lanes > 1u ? ctx->lane[ctx->last.lane] : ctx->stream; // the stream that launch went to
+        if (hipMemcpyAsync(sl.h, sl.d, bytes, hipMemcpyDeviceToHost, s) != hipSuccess || hipEventRecord(sl.done, s) != hipSuccess) { st = RTC_ERR_DEVICE; break; }
+        sl.pending = true;
+        sl.job = i;
+    }
+    {
+        const rtc_status d = drain(i);
+        if (st == RTC_OK) st = d;
+    }
+    const rtc_status sy = rtc_context_synchronize(ctx);
+    if (st == RTC_OK) st = sy;
+    if (world) rtc_world_destroy(world);
+    for (Slot &sl : ring) {
+        if (sl.d) (void)hipFree(sl.d);
+        if (sl.h) (void)hipHostFree(sl.h);
+        if (sl.done) (void)hipEventDestroy(sl.done);
+    }
+    if (ctx->lanes != lanes_before) {
+        const rtc_status r = rtc_context_set_pipeline(ctx, lanes_before);
+        if (st == RTC_OK) st = r;
+    }
+    if (st == RTC_OK && stats) st = rtc_stats_read(ctx, stats);
+    return st;
+}
+
 rtc_status rtc_host_alloc(size_t bytes, void **out) {
     if (!out || bytes == 0) return RTC_ERR_ARG;
     *out = nullptr;

@@ -343,3 +343,81 @@ def test_tile_rows_proven_black_are_skipped_exactly(rtc, scenes, O):
             ctx.close()
         o_img, o_st = O.render(w.array(), len(w), w.light, cam, mode=1, nthreads=8, want_stats=True)
         assert float(np.max(np.abs(o_img - want))) <= 1e-12 and o_st == st_want, kind
+
+
+@pytest.mark.parametrize("which", ["c2_test7", "north_star"])
+def test_whole_frame_1080p_against_the_oracle(rtc, scenes, O, which):
+    """Configs C2 (the reference's `test7` scene, main.rs:204-251) and the north-star world at their FULL 1920x1080 size, every
+    pixel against the CPU oracle (not a sample) with exact ray counts — as bench.py times them: one camera per launch on a
+    pipelined context (depth 3, ring of canvases, binned primary pass, light lists, tile rows proven black), and in order."""
+    import torch
+    W, H = 1920, 1080
+    w, cam = scenes.test7(W, H) if which == "c2_test7" else scenes.synthetic(100, W, H)
+    want, ost = O.render(w.array(), len(w), w.light, cam, mode=1, nthreads=16, want_stats=True)
+    ctx = rtc.Context(0)
+    dw = ctx.upload(w)
+    got, st = dw.render(cam, rtc.MODE_RENDER_ASYNC, with_stats=True)
+    assert st == ost
+    assert float(np.max(np.abs(got - want))) <= 1e-12
+    ctx.set_pipeline(3)
+    ring = [torch.full((H, W, 3), -1.0, dtype=torch.float64, device="cuda:0") for _ in range(4)]
+    torch.cuda.synchronize()
+    ctx.reset_stats()
+    for i in range(8):
+        dw.render_rows(cam, 0, H, ring[i % 4].data_ptr())
+    ctx.synchronize()
+    pst = ctx.stats()
+    assert all(pst[k] == 8 * st[k] for k in st), (pst, st)
+    info = ctx.last_launch_info()
+    assert info["binned_primary_pass"] and info["light_lists"] == (which == "north_star")   # test7's four objects get no lists
+    for r in ring:
+        assert np.array_equal(r.cpu().numpy(), got)
+    dw.close()
+    ctx.close()
+
+
+def test_lua_program_render_orbit_animation(rtc, scenes, O):
+    """rtc_lua_program_render (lua.rs's render_lua on the GPU): the orbit script's 12 AddFrame jobs and its Render job, one
+    launch each on the context's lanes with the frame copies behind them, frames delivered in job order — equal to the
+    same jobs rendered one by one through rtc_render_rgb8 and to Color::scale of the oracle's canvases; ray counts add up;
+    the context is in order again afterwards; a callback can stop the run; a second world in the script is a new upload."""
+    from pathlib import Path
+    data = Path(rtc.__file__).resolve().parent / "data"
+    text = "FRAMES = 5 BALLS = 9 WIDTH, HEIGHT = 200, 136\n" + (data / "orbit_animation.lua").read_text()
+    text += "\ntable.remove(world.shapes, 2)\nRender(world, camera, 'fewer.ppm')\n"          # a different world at the end: no cube
+    prog = rtc.LuaProgram(text=text, base_dir=data)
+    jobs = prog.jobs
+    assert len(jobs) == 7 and [j.same_world_as_previous for j in jobs] == [False, True, True, True, True, True, False]
+    ctx = rtc.Context(0)
+    frames, st = prog.render(ctx, with_stats=True)
+    assert len(frames) == 7 and all(f.shape == (136, 200, 3) and f.dtype == np.uint8 for f in frames)
+    assert ctx.last_launch_info()["lane"] in (0, 1, 2)
+    total = {}
+    for j, f in zip(jobs, frames):
+        dw = ctx.upload(j.world)
+        one, s1 = dw.render_rgb8(j.camera, with_stats=True)
+        dw.close()
+        assert np.array_equal(f, one), j.index
+        for k, v in s1.items():
+            total[k] = total.get(k, 0) + v
+        if j.index in (0, 3, 6):
+            want = O.render(j.world.array(), len(j.world), j.world.light, j.camera, mode=1, nthreads=8)
+            q = rtc.color_scale255(want).reshape(136, 200, 3)
+            diff = np.abs(f.astype(np.int16) - q.astype(np.int16))
+            assert diff.max() <= 1 and np.count_nonzero(diff) <= 4, (j.index, int(diff.max()), int(np.count_nonzero(diff)))   # 1e-12 on a quantisation edge
+    assert all(st[k] == total[k] for k in total if k in st), (st, total)
+    assert not np.array_equal(frames[0], frames[1]) and not np.array_equal(frames[5], frames[6])
+    # in order again: a plain render after it equals the frame
+    dw = ctx.upload(jobs[2].world)
+    assert np.array_equal(dw.render_rgb8(jobs[2].camera), frames[2])
+    dw.close()
+    # a pipelined context keeps its depth
+    ctx.set_pipeline(2)
+    seen = []
+    prog.render(ctx, on_frame=lambda i, frame, outfile, kind: seen.append((i, outfile, kind, frame.copy())) or i == 2)
+    assert [s[0] for s in seen] == [0, 1, 2] and seen[0][1:3] == ("orbit.gif", "AddFrame")
+    assert all(np.array_equal(s[3], frames[s[0]]) for s in seen)
+    ctx.set_pipeline(1)
+    with pytest.raises(ZeroDivisionError):
+        prog.render(ctx, on_frame=lambda *a: 1 // 0)
+    ctx.close()
