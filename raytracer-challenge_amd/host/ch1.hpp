@@ -20,6 +20,8 @@
 #include <array>
 #include <cstdint>
 #include <memory>
+#include <exception>
+#include <type_traits>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -318,6 +320,49 @@ class Camera { // camera.rs:17-160
     }
     rtc_camera flat_{};
 };
+
+namespace detail {
+struct LuaProgramGuard {
+    rtc_lua_program *p;
+    ~LuaProgramGuard() { rtc_lua_program_free(p); }
+};
+template <class Sink>
+struct LuaSink {
+    Sink *sink;
+    std::exception_ptr thrown;
+    static int frame(void *user, const rtc_lua_job *job, uint32_t, const uint8_t *rgb8) {
+        LuaSink *c = static_cast<LuaSink *>(user);
+        try {
+            Canvas canvas = Canvas::quantised(job->camera.hsize, job->camera.vsize);
+            canvas.rgb8.assign(rgb8, rgb8 + canvas.rgb8.size());
+            (*c->sink)(canvas, std::string(job->outfile), job->kind == RTC_LUA_JOB_ADD_FRAME ? static_cast<int>(job->frame) : -1);
+            return 0;
+        } catch (...) { // never unwind through the C library
+            c->thrown = std::current_exception();
+            return 1;
+        }
+    }
+};
+} // namespace detail
+
+// render_lua (lua.rs:50-91): run a scene script and render what it asks for. The reference writes each Render's Canvas
+// with `image` (PNG / JPEG by extension) and each animation as a GIF; those codecs are not rebuilt here, so the frames are
+// handed to `sink` instead — (Canvas holding the 8-bit frame, the file name the script gave, frame number inside its
+// animation or -1 for Render) — in the order the script made the calls. Returns what the script print()ed.
+template <class Sink>
+inline std::string render_lua(const std::string &script, Sink &&sink) {
+    char err[512] = "";
+    rtc_lua_program *prog = nullptr;
+    const rtc_status st = rtc_lua_run_file(script.c_str(), 0, &prog, err, sizeof err);
+    if (st != RTC_OK) throw Panic(st, std::string("render_lua: ") + err); // lua.rs unwrap()s
+    detail::LuaProgramGuard guard{prog};
+    typedef typename std::remove_reference<Sink>::type SinkT;
+    detail::LuaSink<SinkT> ctx{&sink, nullptr};
+    const rtc_status rs = rtc_lua_program_render(Device::get(), prog, RTC_MODE_RENDER_ASYNC, RTC_FLAG_NONE, &detail::LuaSink<SinkT>::frame, &ctx, nullptr);
+    if (ctx.thrown) std::rethrow_exception(ctx.thrown);
+    check(rs, "render_lua");
+    return rtc_lua_program_output(prog);
+}
 
 } // namespace ch1
 #endif
