@@ -322,6 +322,14 @@ void        rtc_color_scale255(const double *components, size_t n, uint8_t *out)
  * f32 as the reference does), alpha 255. Canvas::new sets gamma = 1.0 (canvas.rs:30). `out` holds
  * width*height*4 bytes. Host. */
 void        rtc_canvas_to_rgba8(const double *rgb, uint32_t width, uint32_t height, float gamma, uint8_t *out);
+/* Canvas::write_to_file for a ".png" name (canvas.rs:80-84: to_imgbuf().save(path); the `image` crate encodes by
+ * extension): an 8-bit PNG of `pixels` = height*width*channels bytes, channels = 4 (to_imgbuf's RGBA, colour type 6) or 3
+ * (the device's Color::scale frame, colour type 2; a decoder supplies alpha 255, which is what to_imgbuf stores). PNG is
+ * lossless: decoding gives back exactly these pixels, as it does for the reference's file. No compressor is built in —
+ * the zlib stream uses stored blocks, so the file is a little larger than the pixels. JPEG and GIF (lossy / palette
+ * quantising third-party codecs in the reference) are not rebuilt. format: bytes needed; writes at most cap. Host. */
+rtc_status  rtc_canvas_write_png8(const char *path, const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t channels);
+size_t      rtc_canvas_format_png8(const uint8_t *pixels, uint32_t width, uint32_t height, uint32_t channels, uint8_t *buf, size_t cap);
 
 /* ==== [device] the hot path on one MI355X ========================================== */
 

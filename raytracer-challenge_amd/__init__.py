@@ -326,6 +326,33 @@ class LuaProgram:
             return frames, _stats_dict(st, True)
         return frames
 
+    def render_to_files(self, ctx: "Context", out_dir, mode: int = MODE_RENDER_ASYNC, flags: int = 0) -> list:
+        """render_lua with the files written: Render(world, camera, "x.png") -> out_dir/x.png, "x.ppm" -> the P3 file of
+        Canvas::write_to_file_simple; any other extension (the reference's JPEG / GIF codecs are not rebuilt) -> the name
+        + ".png". AddFrame frames of StartAnimation("a.gif") -> out_dir/a.gif.0000.png, a.gif.0001.png, ...
+        Only the file's base name is used. Returns the paths in job order."""
+        out = Path(out_dir)
+        out.mkdir(parents=True, exist_ok=True)
+        paths = []
+
+        def on_frame(index, frame, outfile, kind):
+            name = Path(outfile).name or f"job{index}"
+            if kind == "AddFrame":
+                target = out / f"{name}.{self.job(index).frame:04d}.png"
+            elif name.lower().endswith((".png", ".ppm")):
+                target = out / name
+            else:
+                target = out / (name + ".png")
+            if target.suffix.lower() == ".ppm":
+                write_ppm_rgb8(target, frame)
+            else:
+                write_png(target, frame)
+            paths.append(target)
+            return False
+
+        self.render(ctx, on_frame=on_frame, mode=mode, flags=flags)
+        return paths
+
     def close(self):
         if getattr(self, "_h", None):
             lib().rtc_lua_program_free(self._h)
@@ -403,6 +430,28 @@ def write_ppm_rgb8(path, rgb8: np.ndarray) -> None:
     a = np.ascontiguousarray(rgb8, dtype=np.uint8)
     _check(lib().rtc_canvas_write_ppm_rgb8(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], a.shape[0]),
            "Canvas.write_to_file_simple (rgb8)")
+
+
+def format_png(pixels: np.ndarray) -> bytes:
+    """An 8-bit PNG (rtc_canvas_format_png8) of a (H, W, 3) or (H, W, 4) uint8 frame — Canvas::write_to_file's ".png" case."""
+    a = np.ascontiguousarray(pixels, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] not in (3, 4):
+        raise ValueError("pixels must be (H, W, 3) or (H, W, 4) uint8")
+    h, w, c = a.shape
+    P8 = C.POINTER(C.c_uint8)
+    need = lib().rtc_canvas_format_png8(a.ctypes.data_as(P8), w, h, c, None, 0)
+    if need == 0:
+        raise ValueError("empty frame")
+    buf = np.empty(need, dtype=np.uint8)
+    lib().rtc_canvas_format_png8(a.ctypes.data_as(P8), w, h, c, buf.ctypes.data_as(P8), need)
+    return buf.tobytes()
+
+
+def write_png(path, pixels: np.ndarray) -> None:
+    a = np.ascontiguousarray(pixels, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] not in (3, 4):
+        raise ValueError("pixels must be (H, W, 3) or (H, W, 4) uint8")
+    _check(lib().rtc_canvas_write_png8(str(path).encode(), a.ctypes.data_as(C.POINTER(C.c_uint8)), a.shape[1], a.shape[0], a.shape[2]), "rtc_canvas_write_png8")
 
 
 def write_ppm(path, rgb: np.ndarray) -> None:
@@ -804,7 +853,7 @@ def group_undeal_host(staging: np.ndarray, nranks: int, nframes: int, vsize: int
 
 
 __all__ = ["lib", "RtcError", "Matrix", "material", "sphere", "plane", "cube", "light", "World", "camera", "ray_for_pixel",
-           "load_yaml", "load_lua", "LuaProgram", "LuaJob", "format_ppm", "write_ppm", "color_scale255", "Context", "DeviceWorld", "MODE_RENDER", "MODE_RENDER_ASYNC", "FLAG_NONE", "FLAG_NO_CULL", "FLAG_AA_RESAMPLE", "Group", "GroupWorld", "group_unique_id",
+           "load_yaml", "load_lua", "LuaProgram", "LuaJob", "format_ppm", "write_ppm", "format_png", "write_png", "color_scale255", "Context", "DeviceWorld", "MODE_RENDER", "MODE_RENDER_ASYNC", "FLAG_NONE", "FLAG_NO_CULL", "FLAG_AA_RESAMPLE", "Group", "GroupWorld", "group_unique_id",
            "host_register", "host_unregister", "host_canvas", "host_canvas_rgb8", "format_ppm_rgb8", "write_ppm_rgb8",
            "group_packed_rows", "group_bands_owned", "group_row_owner", "group_packed_row_to_image", "group_undeal_host", "EXCHANGE_RCCL", "EXCHANGE_P2P", "GATHER_NONE", "GATHER_F64", "GATHER_U8",
            "SPHERE", "PLANE", "CUBE", "RtcCamera", "RtcHit", "RtcLight", "RtcMaterial", "RtcShape", "RtcStats"]

@@ -100,6 +100,8 @@ PROTOTYPES = {
                                         C.POINTER(RtcCamera), C.c_char_p, C.c_size_t]),
     "rtc_scene_load_yaml_file": (C.c_int32, [C.c_char_p, C.POINTER(C.POINTER(RtcShape)), C.POINTER(U32), C.POINTER(RtcLight),
                                              C.POINTER(RtcCamera), C.c_char_p, C.c_size_t]),
+    "rtc_canvas_write_png8": (C.c_int32, [C.c_char_p, C.POINTER(C.c_uint8), U32, U32, U32]),
+    "rtc_canvas_format_png8": (C.c_size_t, [C.POINTER(C.c_uint8), U32, U32, U32, C.POINTER(C.c_uint8), C.c_size_t]),
     "rtc_lua_run": (C.c_int32, [C.c_char_p, C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
     "rtc_lua_run_file": (C.c_int32, [C.c_char_p, C.c_uint64, C.POINTER(C.c_void_p), C.c_char_p, C.c_size_t]),
     "rtc_lua_program_jobs": (C.c_uint32, [C.c_void_p]),

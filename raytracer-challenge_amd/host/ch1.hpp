@@ -20,6 +20,7 @@
 #include <array>
 #include <cstdint>
 #include <memory>
+#include <cctype>
 #include <exception>
 #include <type_traits>
 #include <stdexcept>
@@ -167,6 +168,19 @@ class Canvas { // canvas.rs:16-109
         if (is_quantised()) check(rtc_canvas_write_ppm_rgb8(file_name.c_str(), rgb8.data(), width, height), "Canvas::write_to_file_simple");
         else check(rtc_canvas_write_ppm(file_name.c_str(), pixels.data(), width, height), "Canvas::write_to_file_simple");
     }
+    // Canvas::write_to_file (canvas.rs:80-84): to_imgbuf().save(path), the codec chosen by the extension. PNG is written
+    // (lossless: the same pixels after decoding as the reference's file); the `image` crate's other codecs are not rebuilt.
+    void write_to_file(const std::string &file_name) const {
+        const size_t dot = file_name.find_last_of('.');
+        std::string ext = dot == std::string::npos ? std::string() : file_name.substr(dot + 1);
+        for (char &c : ext) c = static_cast<char>(std::tolower(static_cast<unsigned char>(c)));
+        if (ext != "png") throw Panic(RTC_ERR_ARG, "Canvas::write_to_file(" + file_name + "): only .png is written here (write_to_file_simple: PPM)");
+        if (is_quantised()) { check(rtc_canvas_write_png8(file_name.c_str(), rgb8.data(), width, height, 3), "Canvas::write_to_file"); return; }
+        std::vector<uint8_t> rgba(static_cast<size_t>(width) * height * 4);
+        rtc_canvas_to_rgba8(pixels.data(), width, height, gamma, rgba.data());
+        check(rtc_canvas_write_png8(file_name.c_str(), rgba.data(), width, height, 4), "Canvas::write_to_file");
+    }
+    float gamma = 1.0f; // canvas.rs:30
   private:
     double *at(uint32_t x, uint32_t y) {
         if (is_quantised()) throw std::logic_error("Canvas holds the 8-bit frame only (Camera::render_rgb8): render() for f64 pixels");

@@ -171,6 +171,12 @@ static void test_render_lua(const std::string &script) {
     EXPECT(printed.find("frames: 12") != std::string::npos);
     EXPECT(frames.size() == 13 && frames[0].is_quantised() && frames[0].width == 320 && frames[0].height == 200);
     EXPECT(frames.size() == 13 && frames[0].rgb8 != frames[1].rgb8);
+    if (frames.size() == 13) { // Canvas::write_to_file: PNG of the quantised frame; any other extension panics
+        frames[12].write_to_file(script + ".top.png");
+        bool refused = false;
+        try { frames[12].write_to_file(script + ".top.jpg"); } catch (const Panic &) { refused = true; }
+        EXPECT(refused);
+    }
     bool threw = false;
     try { render_lua(script, [&](const Canvas &, const std::string &, int) { throw std::runtime_error("sink"); }); }
     catch (const std::runtime_error &e) { threw = std::string(e.what()) == "sink"; }

@@ -420,4 +420,12 @@ def test_lua_program_render_orbit_animation(rtc, scenes, O):
     ctx.set_pipeline(1)
     with pytest.raises(ZeroDivisionError):
         prog.render(ctx, on_frame=lambda *a: 1 // 0)
+    # the files: AddFrame frames numbered under the animation's name, Render by extension (.ppm: the P3 writer; other: PNG)
+    from test_gpu_facade import decode_png
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        paths = prog.render_to_files(ctx, d)
+        assert [p.name for p in paths] == [f"orbit.gif.{k:04d}.png" for k in range(5)] + ["orbit_top.ppm", "fewer.ppm"]
+        assert np.array_equal(decode_png(paths[3].read_bytes()), frames[3])
+        assert paths[5].read_bytes() == rtc.format_ppm_rgb8(frames[5])
     ctx.close()

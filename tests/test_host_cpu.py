@@ -723,3 +723,23 @@ def test_lua_require_and_budget(rtc, tmp_path):
     with pytest.raises(rtc.RtcError) as e:
         rtc.LuaProgram(path=tmp_path / "nope.lua")
     assert e.value.status == 6
+
+
+def test_png_writer_round_trips(rtc, tmp_path):
+    """rtc_canvas_write_png8 / _format_png8 (Canvas::write_to_file's ".png" case, canvas.rs:80-84): a standard decoder — chunk
+    CRCs, zlib — gives back exactly the pixels, RGB and RGBA, from 1x1 to rows longer than one stored block."""
+    from test_gpu_facade import decode_png
+    rng = np.random.default_rng(3)
+    for h, w, c in ((1, 1, 3), (7, 5, 4), (200, 333, 3), (64, 96, 4), (2, 70000, 3)):
+        a = rng.integers(0, 256, (h, w, c), dtype=np.uint8)
+        png = rtc.format_png(a)
+        assert np.array_equal(decode_png(png), a), (h, w, c)
+        rtc.write_png(tmp_path / "a.png", a)
+        assert (tmp_path / "a.png").read_bytes() == png
+    canvas = rng.uniform(-0.2, 1.3, (9, 11, 3))
+    assert np.array_equal(decode_png(rtc.format_png(rtc.to_rgba8(canvas)))[:, :, :3], rtc.color_scale255(canvas).reshape(9, 11, 3))
+    with pytest.raises(ValueError):
+        rtc.format_png(np.zeros((4, 4), dtype=np.uint8))
+    with pytest.raises(rtc.RtcError) as e:
+        rtc.write_png(tmp_path / "no" / "dir.png", np.zeros((2, 2, 3), dtype=np.uint8))
+    assert e.value.status == 6
