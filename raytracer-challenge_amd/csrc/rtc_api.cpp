@@ -606,6 +606,7 @@ void rtc_world_destroy(rtc_world *w) {
     for (rtc_world::BinSet &b : w->bin) {
         if (b.tile_cnt) (void)hipFree(b.tile_cnt);
         if (b.tile_list) (void)hipFree(b.tile_list);
+        if (b.prim) (void)hipFree(b.prim);
         if (b.binned) (void)hipEventDestroy(b.binned);
         if (b.traced) (void)hipEventDestroy(b.traced);
     }
@@ -707,11 +708,20 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
                 bin_ok = false;
             }
         }
+        if (bin_ok && B.prim_cap < (size_t)w->n * nviews) {
+            (void)hipStreamSynchronize(stream);
+            if (B.prim) (void)hipFree(B.prim);
+            B.prim = nullptr; B.prim_cap = 0;
+            ++ctx->render_allocs;
+            if (hipMalloc(&B.prim, sizeof(DevPrim) * (size_t)w->n * nviews) == hipSuccess) B.prim_cap = (size_t)w->n * nviews;
+            else { (void)hipGetLastError(); bin_ok = false; }
+        }
         if (bin_ok) {
             HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound_s, w->d_gbound, w->d_orig_s, w->ngroups,
                                        B.tile_cnt + RTC_BIN_ROW_WORDS, B.tile_list, y0 / 8u, band_stride, stream, timed ? pair_bin[0] : nullptr,
-                                       timed ? pair_bin[1] : nullptr, w->d_isect_s, w->d_kind_s, w->n_unb, B.tile_cnt));
+                                       timed ? pair_bin[1] : nullptr, w->d_isect_s, w->d_kind_s, w->n_unb, B.tile_cnt, w->d_isect, B.prim));
             if (timed) ctx->bin_timed[slot] = true;
+            P.prim = B.prim;
             P.tile_rows = ctx->sky_rows ? B.tile_cnt : nullptr;
             P.tile_cnt = B.tile_cnt + RTC_BIN_ROW_WORDS;
             P.tile_list = B.tile_list;
@@ -752,6 +762,14 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
                     bin_ok = false;
                 }
             }
+            if (bin_ok && S.prim_cap < (size_t)w->n * nviews) {
+                if (S.prim) (void)hipFree(S.prim);
+                S.prim = nullptr; S.prim_cap = 0;
+                ++ctx->render_allocs;
+                const size_t want = (size_t)w->n * std::max(alloc_views, nviews);
+                if (hipMalloc(&S.prim, sizeof(DevPrim) * want) == hipSuccess) S.prim_cap = want;
+                else { (void)hipGetLastError(); bin_ok = false; }
+            }
         }
     }
     if (bin_ok && !piped) {
@@ -762,8 +780,9 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
         HIP_TRY(hipStreamWaitEvent(ctx->side_stream, B.traced, 0)); // never recorded: no wait
         HIP_TRY(rtc_launch_binning(P.views, nviews, cam->hsize, cam->vsize, w->n, w->d_bound_s, w->d_gbound, w->d_orig_s, w->ngroups,
                                    B.tile_cnt + RTC_BIN_ROW_WORDS, B.tile_list, y0 / 8u, band_stride, ctx->side_stream, timed ? pair_bin[0] : nullptr,
-                                   timed ? pair_bin[1] : nullptr, w->d_isect_s, w->d_kind_s, w->n_unb, B.tile_cnt));
+                                   timed ? pair_bin[1] : nullptr, w->d_isect_s, w->d_kind_s, w->n_unb, B.tile_cnt, w->d_isect, B.prim));
         if (timed) ctx->bin_timed[slot] = true;
+        P.prim = B.prim;
         HIP_TRY(hipEventRecord(B.binned, ctx->side_stream));
         HIP_TRY(hipStreamWaitEvent(ctx->stream, B.binned, 0));
         P.tile_rows = ctx->sky_rows ? B.tile_cnt : nullptr;

@@ -88,6 +88,8 @@ struct rtc_world {
     struct BinSet {
         uint32_t *tile_cnt = nullptr, *tile_list = nullptr; // per (view, tile): entries used, RTC_TILE_LIST_CAP entry slots (tile_cnt: RTC_BIN_ROW_WORDS row words first)
         size_t tiles_cap = 0;            // capacity in (view, tile) entries
+        DevPrim *prim = nullptr;         // per (view, object): the primary rays' constants, written by the set's binning kernel
+        size_t prim_cap = 0;             // capacity in records
         hipEvent_t binned = nullptr;     // recorded on the side stream after the set's binning kernel
         hipEvent_t traced = nullptr;     // recorded on the render stream after the render kernel that read the set
     };
@@ -108,7 +110,8 @@ struct rtc_world {
 extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound_s,
                                          const DevBound *gbound, const uint32_t *orig_s, uint32_t ngroups, uint32_t *cnt, uint32_t *list,
                                          uint32_t row0, uint32_t row_stride, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
-                                         const DevIsect *isect_s, const uint32_t *kind_s, uint32_t n_unb, uint32_t *rows);
+                                         const DevIsect *isect_s, const uint32_t *kind_s, uint32_t n_unb, uint32_t *rows,
+                                         const DevIsect *isect, DevPrim *prim);
 enum { RTC_BIN_ROW_WORDS = 2 * RTC_MAX_VIEWS }; // a BinSet's tile_cnt buffer starts with the views' row words (RenderParams::tile_rows)
 extern "C" hipError_t rtc_launch_light_lists(uint32_t n, uint32_t cap, const DevBound *bound, const double light[3], double reach, DevTileBundle *cells,
                                              DevTileBundle *macros, uint32_t *cnt, uint32_t *list, hipStream_t stream);

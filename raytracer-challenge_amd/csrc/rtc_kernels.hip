@@ -53,6 +53,11 @@
 #ifndef RTC_BIN_HOIST
 #define RTC_BIN_HOIST 0
 #endif
+// Binned primary pass: the exact tests take the camera origin in object space and the sphere's c from the table the binning
+// kernel wrote for the view (1: closest_prim, 24 VALU instructions fewer per sphere test) or transform the origin again (0).
+#ifndef RTC_BIN_PRIM
+#define RTC_BIN_PRIM 1
+#endif
 // Canvas stores (written once, never read by the kernel): plain (0) or non-temporal (1).
 #ifndef RTC_NT_STORE
 #define RTC_NT_STORE 1
@@ -1400,10 +1405,18 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
             } else if (IS_CULL(SRC) && !PROBE && use_bins) {
                 // binned primary pass: the unbounded objects, then the tile's own list (k_bin_tiles) — together
                 // every object this tile's rays can touch
+                // (the view's primary-ray constants come from the binning kernel's table: only the direction is transformed)
                 const auto &Pb = KP(P_arg);
+                const DevPrim *__restrict__ vprim = T.prim + (size_t)view * Pb.n;
+#if RTC_BIN_PRIM
+#define RTC_BINNED_TEST(KIND, M, J) closest_prim(KIND, M, reinterpret_cast<const double *>(vprim + (J)), rd, (int)(J), best, hidx, hroot)
+#else
+#define RTC_BINNED_TEST(KIND, M, J) closest_world(KIND, M, ro, rd, (int)(J), best, hidx, hroot)
+#endif
                 for (uint32_t k = 0; k < Pb.n_unb; ++k) {
                     DIAG(2, 1u);
-                    if (tracing) closest_world(T.kind_s[k], T.isect_s[k].m, ro, rd, (int)T.orig_s[k], best, hidx, hroot);
+                    const uint32_t jo = T.orig_s[k];
+                    if (tracing) RTC_BINNED_TEST(T.kind_s[k], T.isect_s[k].m, jo);
                 }
                 // the tile's list, nearest first: lane e holds entry e and the lower bound of the distance from the camera to
                 // its (inflated) bounding sphere — every intersection of that object has t >= key for these unit-direction
@@ -1420,7 +1433,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                         if (ent == e) ent = 0xffffffffu;
                         const uint32_t j = e & 0xffffu;
                         DIAG(2, 1u);
-                        if (tracing) closest_world(T.kind[j], T.isect[j].m, ro, rd, (int)j, best, hidx, hroot);
+                        if (tracing) RTC_BINNED_TEST(T.kind[j], T.isect[j].m, j);
                     }
                 } else { // more than 65 536 objects: plain indices, keys from the bounds
                     uint32_t my_j = 0u;
@@ -1436,7 +1449,7 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
                         if (ballot(tracing && !(best < (double)kmin)) == 0ull) break;
                         const uint32_t j = (uint32_t)__builtin_amdgcn_readlane((int)my_j, sel);
                         DIAG(2, 1u);
-                        if (tracing) closest_world(T.kind[j], T.isect[j].m, ro, rd, (int)j, best, hidx, hroot);
+                        if (tracing) RTC_BINNED_TEST(T.kind[j], T.isect[j].m, j);
                     }
                 }
             } else if (SRC == SRC_CULL2 && !PROBE && shared_origin && first) {
@@ -2093,6 +2106,15 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
 
 // Per-render prologue: camera origin in each object's space and the sphere quadratic's `c`
 // (shape.rs:363,366) — the part of every primary-ray test that does not depend on the pixel.
+DEVI DevPrim prim_of(const double *m_obj, V3 origin) { // (file scope: never under a contraction pragma — parity arithmetic)
+    const V3 o = xpoint(m_obj, origin);
+    DevPrim r;
+    r.ox = o.x;
+    r.oy = o.y;
+    r.oz = o.z;
+    r.c = vdot(o, o) - 1.;
+    return r;
+}
 __global__ void __launch_bounds__(256) k_prep_primary(const DevIsect *isect, DevPrim *prim, uint32_t n,
                                                             double v0, double v1, double v2, double v3, double v4,
                                                             double v5, double v6, double v7, double v8, double v9,
@@ -2100,12 +2122,7 @@ __global__ void __launch_bounds__(256) k_prep_primary(const DevIsect *isect, Dev
     const uint32_t j = blockIdx.x * 256u + threadIdx.x;
     if (j >= n) return;
     const double vinv[12] = {v0, v1, v2, v3, v4, v5, v6, v7, v8, v9, v10, v11};
-    const V3 origin = xpoint(vinv, mk(0., 0., 0.));
-    const V3 o = xpoint(isect[j].m, origin);
-    prim[j].ox = o.x;
-    prim[j].oy = o.y;
-    prim[j].oz = o.z;
-    prim[j].c = vdot(o, o) - 1.;
+    prim[j] = prim_of(isect[j].m, xpoint(vinv, mk(0., 0., 0.)));
 }
 
 // Device arithmetic probe (rtc_device_arith).
@@ -2248,9 +2265,16 @@ DEVI bool cone_misses_plane(const double *m, V3 o, const DevTileBundle &t) {
 __global__ void __launch_bounds__(64) k_bin_tiles(const BinParams Q, const DevBound *__restrict__ bound_s, const DevBound *__restrict__ gbound,
                                                    const uint32_t *__restrict__ orig_s, uint32_t ngroups, uint32_t *__restrict__ cnt,
                                                    uint32_t *__restrict__ list, const DevIsect *__restrict__ isect_s,
-                                                   const uint32_t *__restrict__ kind_s, uint32_t n_unb, uint32_t *__restrict__ rows) {
+                                                   const uint32_t *__restrict__ kind_s, uint32_t n_unb, uint32_t *__restrict__ rows,
+                                                   const DevIsect *__restrict__ isect, DevPrim *__restrict__ prim) {
     const uint32_t macros = Q.macros_x * Q.macros_y;
     const uint32_t view = blockIdx.x / macros, m = blockIdx.x % macros, lane = threadIdx.x;
+    // The view's per-object primary-ray constants (camera origin in object space, the sphere's c: k_prep_primary's table,
+    // same arithmetic) for the render kernel's binned pass, spread over all the view's binning threads.
+    if (prim != nullptr) {
+        const V3 cam = xpoint(Q.views[view].vinv, mk(0., 0., 0.));
+        for (uint32_t j = m * 64u + lane; j < Q.n; j += macros * 64u) prim[(size_t)view * Q.n + j] = prim_of(isect[j].m, cam);
+    }
     const uint32_t mx = m % Q.macros_x, my = m / Q.macros_x;
     const uint32_t tx = mx * 8u + (lane & 7u), ty = my * 8u + (lane >> 3);
     const bool mine = tx < Q.tiles_x && ty < Q.tiles_y && ty >= Q.row0 && (ty - Q.row0) % Q.row_stride == 0u;
@@ -2330,7 +2354,8 @@ __global__ void __launch_bounds__(64) k_bin_tiles(const BinParams Q, const DevBo
 extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews, uint32_t W, uint32_t H, uint32_t n, const DevBound *bound_s,
                                          const DevBound *gbound, const uint32_t *orig_s, uint32_t ngroups, uint32_t *cnt, uint32_t *list,
                                          uint32_t row0, uint32_t row_stride, hipStream_t stream, hipEvent_t e0, hipEvent_t e1,
-                                         const DevIsect *isect_s, const uint32_t *kind_s, uint32_t n_unb, uint32_t *rows) {
+                                         const DevIsect *isect_s, const uint32_t *kind_s, uint32_t n_unb, uint32_t *rows,
+                                         const DevIsect *isect, DevPrim *prim) {
     if (n == 0) return hipSuccess;
     if (hipMemsetAsync(rows, 0xff, sizeof(uint32_t) * 2u * RTC_MAX_VIEWS, stream) != hipSuccess) return hipGetLastError();
     BinParams Q;
@@ -2343,7 +2368,7 @@ extern "C" hipError_t rtc_launch_binning(const DevCamera *views, uint32_t nviews
     Q.macros_x = (Q.tiles_x + 7u) / 8u; Q.macros_y = (Q.tiles_y + 7u) / 8u;
     // e0/e1 (may be NULL): the dispatch's own begin/end timestamps, as for k_trace
     hipExtLaunchKernelGGL(k_bin_tiles, dim3(nviews * Q.macros_x * Q.macros_y), dim3(64), 0, stream, e0, e1, 0, Q, bound_s, gbound, orig_s, ngroups, cnt, list,
-                          isect_s, kind_s, n_unb, rows);
+                          isect_s, kind_s, n_unb, rows, isect, prim);
     return hipGetLastError();
 }
 
