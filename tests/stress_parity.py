@@ -1,6 +1,7 @@
 """One-off stress campaign (not part of the test suite): many random adversarial worlds, the culled
 kernels (one- and two-level) against plain brute force on the GPU, bit for bit (canvas + ray counts);
-every 10th world also against the CPU oracle. Usage: python tests/stress_parity.py [n_worlds] [seed0]"""
+every 10th world also against the CPU oracle. Usage: python tests/stress_parity.py [n_worlds] [seed0] [pipeline_depth]
+(RTC_BIN_SMALL_PIXELS=0 / RTC_BIN_SMALL_PIXELS_PIPELINED=0 in the environment force the binned primary pass on these small frames.)"""
 import importlib
 import os
 import sys
@@ -19,6 +20,7 @@ from test_gpu_parity import adversarial_scene  # noqa: E402
 
 n_worlds = int(sys.argv[1]) if len(sys.argv) > 1 else 300
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
+pipeline = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 
 
 def big_world(seed):
@@ -103,6 +105,8 @@ def mirror_world(seed):
 
 
 ctx = rtc.Context(0)
+if pipeline > 1:
+    ctx.set_pipeline(pipeline)
 bad = 0
 t0 = time.time()
 for k in range(n_worlds):
