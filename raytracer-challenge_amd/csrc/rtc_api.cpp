@@ -900,6 +900,17 @@ rtc_status rtc_stats_reset(rtc_context *ctx) {
 
 rtc_status rtc_context_set_timing(rtc_context *ctx, uint32_t every) {
     if (!ctx) return RTC_ERR_ARG;
+    if (every != 0) { // a caller that asks for timings gets the first 64 event pairs now, not 16 at a time in the middle of its timed loop
+        HIP_TRY(hipSetDevice(ctx->device));
+        const uint32_t upto = std::min<uint32_t>(rtc_context::EV_RING, 64u);
+        for (uint32_t k = ctx->ev_created; k < upto; ++k) {
+            HIP_TRY(hipEventCreate(&ctx->ev[k][0]));
+            HIP_TRY(hipEventCreate(&ctx->ev[k][1]));
+            HIP_TRY(hipEventCreate(&ctx->ev_bin[k][0]));
+            HIP_TRY(hipEventCreate(&ctx->ev_bin[k][1]));
+            ctx->ev_created = k + 1;
+        }
+    }
     ctx->time_every = every;
     ctx->launches = 0; // the next launch is sampled (if any is), and the ring starts afresh
     ctx->timed = 0;
