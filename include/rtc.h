@@ -269,7 +269,8 @@ rtc_status  rtc_scene_load_yaml_file(const char *path, rtc_shape **shapes_out, u
  * the jobs in order (one rtc_render* launch each: an AddFrame loop is the one-camera-per-launch sequence a pipelined
  * context overlaps); encoding GIF / PNG / JPEG files is the `image` crate's business in the reference and nobody's here.
  * math.random is Lua 5.3's on POSIX (glibc random(), restated), so `math.randomseed(13)` worlds are reproducible.
- * A script runs under a step budget (`step_limit` statements / loop iterations / calls, 0 = 100 000 000) and cannot touch
+ * A script runs under a step budget (`step_limit` statements / loop iterations / calls, 0 = 100 000 000), may nest 200 calls
+ * (the interpreter recurses on the caller's stack: up to about 2 MB of it at that depth) and cannot touch
  * the file system except through require (`base_dir`/name.lua; NULL = require is an error). Syntax and runtime errors,
  * and tables lua.rs would reject, are RTC_ERR_PARSE with the message in errbuf (the reference unwrap()s: it panics).
  * PARITY UNPINNED: the reference has no test of its Lua path. [host] */

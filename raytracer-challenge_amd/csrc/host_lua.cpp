@@ -1082,8 +1082,9 @@ struct Interp {
         if (fn.kind != Value::Fun) fail(line, std::string("attempt to call a ") + type_name(fn) + " value" + (what.empty() ? "" : " (" + what + ")"));
         tick(line);
         if (fn.f->native) { fn.f->native(*this, args, rets, line); return; }
-        if (++call_depth > 160) { --call_depth; fail(line, "stack overflow (function calls nested deeper than 160)"); }
+        if (++call_depth > 200) { --call_depth; fail(line, "stack overflow (function calls nested deeper than 200)"); }
         struct Pop { int &d; ~Pop() { --d; } } pop{call_depth};
+        CDepth guard(c_depth, line), guard2(c_depth, line), guard3(c_depth, line); // (a call's own frames)
         auto env = std::make_shared<Env>();
         env->parent = fn.f->env;
         const FuncBody &body = *fn.f->body;
@@ -1133,7 +1134,17 @@ struct Interp {
             else out.push_back(eval(*list[k], env));
         }
     }
+    // C stack: a nested call costs about 4 KB of it, a nested expression level about 0.3 KB; both count against one bound
+    // (200 calls of ordinary expressions, or fewer calls of deeply parenthesised ones: well under 2 MB either way).
+    int c_depth = 0;
+    struct CDepth {
+        int &d;
+        CDepth(int &depth, int line) : d(depth) { if (++d > 2400) { --d; fail(line, "stack overflow (expressions and calls nested too deeply)"); } }
+        ~CDepth() { --d; }
+    };
     Value eval(const Expr &e, const std::shared_ptr<Env> &env) {
+        if (e.kind == Expr::Const) return e.value;
+        CDepth guard(c_depth, e.line);
         switch (e.kind) {
         case Expr::Const: return e.value;
         case Expr::Paren: return eval(*e.a, env);
@@ -1252,9 +1263,18 @@ struct Interp {
                 assign(*s.targets[0], eval(*s.exprs[0], env), env);
                 return FLOW_NORMAL;
             }
+            // "In a multiple assignment, Lua first evaluates all values and only then executes the assignments" (manual 3.3.3):
+            // in `i, a[i] = i + 1, 20` the i of a[i] is the old one — table and key of every indexed target are taken first.
+            std::vector<std::pair<Value, Value>> where(s.targets.size());
+            for (size_t k = 0; k < s.targets.size(); ++k)
+                if (s.targets[k]->kind == Expr::Index) where[k] = {eval(*s.targets[k]->a, env), eval(*s.targets[k]->b, env)};
             Values vs;
             eval_list(s.exprs, env, vs);
-            for (size_t k = 0; k < s.targets.size(); ++k) assign(*s.targets[k], k < vs.size() ? vs[k] : Value{}, env);
+            for (size_t k = 0; k < s.targets.size(); ++k) {
+                const Value v = k < vs.size() ? vs[k] : Value{};
+                if (s.targets[k]->kind == Expr::Index) setindex(where[k].first, where[k].second, v, s.targets[k]->line, describe(*s.targets[k]->a));
+                else assign(*s.targets[k], v, env);
+            }
             return FLOW_NORMAL;
         }
         case Stmt::CallStmt: {
@@ -1613,7 +1633,7 @@ struct Interp {
                 for (auto &v : rets) r.push_back(std::move(v));
             } catch (const LuaError &e) {
                 if (in.steps > in.step_limit) throw; // the budget is not catchable
-                in.call_depth = depth;
+                in.call_depth = depth; // (c_depth unwinds with its guards)
                 in.ret.clear();
                 r.clear();
                 r.push_back(Value::boolean(false));
@@ -1653,7 +1673,7 @@ struct Interp {
             std::fclose(f);
             if (text.find('\0') != std::string::npos) fail(line, "module '" + name + "' is not a text file");
             in.loaded[name] = Value::boolean(true); // a module that requires itself does not recurse
-            if (++in.call_depth > 160) { --in.call_depth; fail(line, "stack overflow (require nested too deeply)"); }
+            if (++in.call_depth > 200) { --in.call_depth; fail(line, "stack overflow (require nested too deeply)"); }
             Values out;
             try { out = in.run_chunk(text.c_str(), rel + ".lua"); } catch (...) { --in.call_depth; throw; }
             --in.call_depth;

@@ -510,6 +510,8 @@ def test_lua_reference_programs_when_present(rtc):
     ("setmetatable({}, {})", "metatables are not supported"),
     ("require('functions')", "require needs the script's directory"),
     ("local function f() return f() end f()", "stack overflow"),
+    ("local function f(n) if n == 0 then return " + "(" * 150 + "0" + ")" * 150 + " end return " + "(" * 150 + "1 + f(n - 1)" + ")" * 150 + " end f(198)", "nested too deeply"),
+    ("x = " + "(" * 400 + "1" + ")" * 400, "too many syntax levels"),
     ("error('made up')", "made up"),
     ("StartAnimation('a.gif'):AddFrame({}, 1)", "AddFrame expects (world table, camera table)"),
     ("Render({}, {})", "Render expects (world table, camera table, output file name)"),
@@ -572,6 +574,7 @@ local function counter() local c = 0 return function() c = c + 1 return c end en
 local c1, c2 = counter(), counter() c1() c1() print(c1(), c2())
 local shadow = 1 do local shadow = 2 print(shadow) end print(shadow)
 x, y = 1, 2 x, y = y, x print(x, y) local q = { 1, 2 } q[1], q[2] = q[2], q[1] print(q[1], q[2])
+do local i, a = 3, {} i, a[i] = i + 1, 20 print(i, a[3], a[4]) end
 for i = 3, 1 do print("never") end for i = 1, 3 do if i == 2 then goto_like = i break end end print(goto_like)
 print(#"", ("%d items"):format(3), [[long
 string]], "tab\there", '\65\066', "a" < "B", 1 == "1", math.pi)
@@ -606,6 +609,7 @@ false\tline 17: boom
 1
 2\t1
 2\t1
+4\t20\tnil
 2
 0\t3 items\tlong
 string\ttab\there\tAB\tfalse\tfalse\t3.1415926535898
