@@ -104,6 +104,14 @@ struct Table {
     std::vector<std::pair<std::string, Value>> fields;
     std::unordered_map<std::string, size_t> index;
     std::map<long long, Value> array;
+    // memory budget of the script that made the table (Interp::mem): 4 units per live table + 1 per entry, returned when it dies
+    std::shared_ptr<long long> mem;
+    long long units = 0;
+    void charge(long long n) { units += n; if (mem) *mem += n; }
+    Table() = default;
+    Table(const Table &) = delete;
+    Table &operator=(const Table &) = delete;
+    ~Table() { if (mem) *mem -= units; }
     const Value *get(const std::string &k) const {
         auto it = index.find(k);
         if (it == index.end()) return nullptr;
@@ -116,14 +124,18 @@ struct Table {
         if (v.kind == Value::Nil) return;
         index.emplace(k, fields.size());
         fields.emplace_back(k, v);
+        charge(1);
     }
     const Value *at(long long k) const {
         auto it = array.find(k);
         return it != array.end() ? &it->second : nullptr;
     }
     void seti(long long k, const Value &v) {
-        if (v.kind == Value::Nil) array.erase(k);
-        else array[k] = v;
+        if (v.kind == Value::Nil) { charge(-static_cast<long long>(array.erase(k))); return; }
+        auto it = array.find(k);
+        if (it != array.end()) { it->second = v; return; }
+        array.emplace(k, v);
+        charge(1);
     }
     long long length() const { // a border: t[n] ~= nil and t[n+1] == nil, counted from 1
         if (array.empty()) return 0;
@@ -876,8 +888,24 @@ struct Interp {
     // while the script runs is registered here and emptied when the program is freed.
     std::vector<std::weak_ptr<Table>> all_tables;
     std::vector<std::weak_ptr<Function>> all_functions;
+    // Live tables and entries of the script, in units of roughly 150 bytes: a loop that builds tables for ever stops here
+    // long before the step budget would stop it (100 M steps could hold 15 GB).
+    std::shared_ptr<long long> mem = std::make_shared<long long>(0);
+    long long mem_limit = 8000000; // about 1 GB; a world of 100 000 shapes is about 1.5 M units
+    void check_mem(int line) {
+        if (*mem > mem_limit) fail(line, "the script exceeded its memory budget (" + std::to_string(mem_limit) + " live tables / entries)");
+    }
     std::shared_ptr<Table> new_table() {
         auto t = std::make_shared<Table>();
+        t->mem = mem;
+        t->charge(4);
+        if (all_tables.size() >= 4096 && all_tables.size() == all_tables.capacity()) { // drop the dead ones before the registry grows
+            size_t keep = 0;
+            for (auto &w : all_tables)
+                if (!w.expired()) all_tables[keep++] = std::move(w);
+            all_tables.resize(keep);
+            if (all_tables.capacity() < 2 * keep + 4096) all_tables.reserve(2 * keep + 4096);
+        }
         all_tables.push_back(t);
         return t;
     }
@@ -885,6 +913,13 @@ struct Interp {
         Value v;
         v.kind = Value::Fun;
         v.f = std::make_shared<Function>();
+        if (all_functions.size() >= 4096 && all_functions.size() == all_functions.capacity()) {
+            size_t keep = 0;
+            for (auto &w : all_functions)
+                if (!w.expired()) all_functions[keep++] = std::move(w);
+            all_functions.resize(keep);
+            if (all_functions.capacity() < 2 * keep + 4096) all_functions.reserve(2 * keep + 4096);
+        }
         all_functions.push_back(v.f);
         return v;
     }
@@ -1068,6 +1103,7 @@ struct Interp {
         if (!normalise_key(key, is_int, ik)) fail(line, std::string("a ") + (key.kind == Value::Num ? "fractional number" : type_name(key)) + " table key is not supported by this interpreter");
         if (is_int) obj.t->seti(ik, v);
         else obj.t->set(key.s, v);
+        check_mem(line);
     }
 
     // ---- calls
@@ -1168,6 +1204,7 @@ struct Interp {
         }
         case Expr::TableCons: {
             auto t = new_table();
+            check_mem(e.line);
             long long next_index = 1;
             for (size_t k = 0; k < e.items.size(); ++k) {
                 const TableItem &it = e.items[k];
@@ -1209,7 +1246,12 @@ struct Interp {
             case OP_LE: return Value::boolean(less(a, b, true, e.line));
             case OP_GT: return Value::boolean(less(b, a, false, e.line));
             case OP_GE: return Value::boolean(less(b, a, true, e.line));
-            case OP_CONCAT: return Value::str(concat_piece(a, e.line) + concat_piece(b, e.line));
+            case OP_CONCAT: {
+                std::string r = concat_piece(a, e.line);
+                r += concat_piece(b, e.line);
+                if (r.size() > (size_t(1) << 26)) fail(e.line, "resulting string too large");
+                return Value::str(std::move(r));
+            }
             default: return arith(e.op, a, b, e.line);
             }
         }

@@ -727,6 +727,14 @@ def test_lua_require_and_budget(rtc, tmp_path):
     with pytest.raises(rtc.RtcError) as e:
         rtc.LuaProgram(path=tmp_path / "nope.lua")
     assert e.value.status == 6
+    # memory: tables that stay alive count against a budget, garbage does not; strings cannot double for ever
+    with pytest.raises(rtc.RtcError) as e:
+        rtc.LuaProgram(text="local t = {} for i = 1, 100000000 do t[i] = {i} end")
+    assert e.value.status == 5 and "memory budget" in str(e.value)
+    assert rtc.LuaProgram(text="for i = 1, 3000000 do local t = {i, i} end local f for i = 1, 300000 do f = function() return i end end print(f())").output == "300000\n"
+    with pytest.raises(rtc.RtcError) as e:
+        rtc.LuaProgram(text="local s = 'x' while true do s = s .. s end")
+    assert "string too large" in str(e.value)
 
 
 def test_png_writer_round_trips(rtc, tmp_path):
