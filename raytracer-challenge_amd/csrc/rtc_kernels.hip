@@ -224,7 +224,7 @@ DEVI V3 xvector3(const double *m, V3 v) {
               m[6] * v.x + m[7] * v.y + m[8] * v.z);
 }
 
-DEVI unsigned long long ballot(bool p) { return __ballot(p ? 1 : 0); }
+DEVI unsigned long long ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
 DEVI uint32_t popc64(unsigned long long m) { return (uint32_t)__popcll(m); }
 
 // Cube::check_axis shape.rs:540-564
@@ -665,6 +665,17 @@ DEVI bool ray_touches_pre(V3 o, V3 d, double dd, const DevPre &b) {
     const double pm = fmax(wx * d.x + wy * d.y + wz * d.z, 0.);
     return !(ww * dd - pm * pm > (b.R2 + 1e-11 * ww) * dd); // NaN-safe: keep unless provably far; R2 = inf: never culled
 }
+// The same test as the MASK of the active lanes it keeps: the compare writes the wave's mask directly (v_cmp -> SGPR pair), where
+// ballot(bool) of a value that lives across blocks costs a v_cndmask 0/1 and a second compare. Used in the batched walk of the
+// one-level kernels (C4 -1.1 %, reflective 1080p -1.4 %); the same form in the two-level kernels' walks and in the binned walk's
+// early-out measured 3 % SLOWER on C3 / C5 (profiles/r03_exp_small_steps.log) and is not used there.
+DEVI unsigned long long ray_touches_pre_mask(V3 o, V3 d, double dd, const DevPre &b) {
+#pragma clang fp contract(fast) // cull arithmetic
+    const double wx = b.cx - o.x, wy = b.cy - o.y, wz = b.cz - o.z;
+    const double ww = wx * wx + wy * wy + wz * wz;
+    const double pm = fmax(wx * d.x + wy * d.y + wz * d.z, 0.);
+    return __builtin_amdgcn_fcmp(ww * dd - pm * pm, (b.R2 + 1e-11 * ww) * dd, 13 /* ULE: !(lhs > rhs) */);
+}
 // Candidates of a per-lane-filtered walk are taken RTC_PRE_BATCH at a time: their records are requested together and their
 // prefilters evaluated back to back before any exact test, so that a pass over many candidates — a secondary pass whose bundle
 // cannot be bounded visits all 101 objects of the reflective north star — is not one scalar-load round trip per object
@@ -757,6 +768,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
         fdd = frd.x * frd.x + frd.y * frd.y + frd.z * frd.z;
     }
     if constexpr (SRC == SRC_CULL) {
+        const unsigned long long needs_mask = ballot(lane_needs); // (lane_needs does not change during the walk)
         // One-level cull (small worlds): up to RTC_OBJ_SLOTS x 64 objects per round, each lane tests one object's sphere of
         // every slot against the wave's bundle (the slots' loads are in flight together: one load -> test -> ballot
         // dependency chain per round instead of one per 64 objects); the ballot masks are walked in ascending
@@ -797,8 +809,7 @@ DEVI void for_each_object(const PP &P, const Tables &T, const LdsView &L, bool l
 #pragma unroll
                             for (uint32_t k = 0; k < RTC_PRE_BATCH; ++k) {
                                 DIAG_FILTER(nfilt);
-                                const bool t = ray_touches_pre(fro, frd, fdd, q[k]); // (evaluated by every lane: no branch around the loads)
-                                bx[k] = ballot(lane_needs & t);
+                                bx[k] = ray_touches_pre_mask(fro, frd, fdd, q[k]) & needs_mask; // (evaluated by every lane: no branch around the loads)
                             }
 #pragma unroll
                             for (uint32_t k = 0; k < RTC_PRE_BATCH; ++k) {
