@@ -269,6 +269,10 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 16) ctx->tiles_per_wg = (uint32_t)v;
     }
+    if (const char *e = std::getenv("RTC_TILES_SPLIT")) { // per cent of a launch's tiles rendered two per workgroup (RenderParams::split)
+        const long v = std::strtol(e, nullptr, 10);
+        if (v >= 0 && v <= 100) ctx->tiles_split_pct = (uint32_t)v;
+    }
     if (const char *e = std::getenv("RTC_TILE_CAP")) {
         const int v = std::atoi(e);
         if (v >= 16 && v <= 1024) ctx->tile_cap = (uint32_t)v;
@@ -798,11 +802,13 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.views[0].vinv, stream));
     P.total_blocks = P.grid_x * P.grid_y * nviews;
     P.reps = ctx->tiles_per_wg;
-    HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, (P.total_blocks + P.reps - 1u) / P.reps, lds_bytes, stream,
+    // (only launches of several rounds of workgroups: a launch the chip holds at once would just get a longer critical path)
+    P.split = (P.reps == 1u && P.total_blocks >= 8192u) ? (uint32_t)((unsigned long long)P.total_blocks * ctx->tiles_split_pct / 200u) : 0u;
+    HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.split ? P.total_blocks - P.split : (P.total_blocks + P.reps - 1u) / P.reps, lds_bytes, stream,
                              timed ? pair[0] : nullptr, timed ? pair[1] : nullptr));
     if (binset) HIP_TRY(hipEventRecord(binset->traced, ctx->stream));
     ctx->last = rtc_launch_info{(uint32_t)src, (w->any_refl || w->any_refr) ? 1u : 0u, w->any_refr ? 1u : 0u, P.tile_cnt ? 1u : 0u,
-                                P.light_cnt ? 1u : 0u, lane, block, (uint32_t)lds_bytes, P.reps, {0u, 0u, 0u}};
+                                P.light_cnt ? 1u : 0u, lane, block, (uint32_t)lds_bytes, P.reps, P.split, {0u, 0u}};
     ++ctx->launches_total;
     // rtc_stats::pixels is known here (the kernel traces exactly the pixels of this launch's rows; Camera::render leaves the
     // last row and column alone, camera.rs:120-121): counted on the host, one atomic per wave less
@@ -1207,6 +1213,7 @@ rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays
         P.flags = flags;
         P.total_blocks = P.grid_x;
         P.reps = 1;
+        P.split = 0;
         if (rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x, lds_bytes, ctx->stream, nullptr,
                              nullptr) != hipSuccess)
             st = RTC_ERR_DEVICE;

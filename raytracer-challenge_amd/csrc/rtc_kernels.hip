@@ -1160,10 +1160,11 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     // A workgroup renders `reps` tiles, one after the other: tile ids blockIdx.x, blockIdx.x + gridDim.x, ... (consecutive
     // workgroups still land on consecutive XCDs). The canvas stores of tile k then drain while tile k+1 is traced (a wave cannot
     // retire before its stores are acknowledged), and the per-wave set-up and the counter atomics are paid once per `reps` tiles.
-    const uint32_t reps = PROBE ? 1u : P.reps;
+    const uint32_t split = PROBE ? 0u : P.split;
+    const uint32_t reps = PROBE ? 1u : (split ? (blockIdx.x < split ? 2u : 1u) : P.reps);
     for (uint32_t rep = 0; rep < reps; ++rep) {
     // workgroup id -> tile: see RTC_TILE_ORDER (XCD balance beats XCD locality here)
-    uint32_t bid = blockIdx.x + rep * gridDim.x;
+    uint32_t bid = split ? ((rep == 0u && blockIdx.x < split) ? blockIdx.x : blockIdx.x + split) : blockIdx.x + rep * gridDim.x;
     if (!PROBE && bid >= P.total_blocks) break; // (workgroup-uniform)
 #if RTC_TILE_ORDER == 0
     {
