@@ -460,9 +460,10 @@ typedef struct rtc_launch_info {
     uint32_t block;       /* threads per workgroup                                                                  */
     uint32_t lds_bytes;   /* dynamic LDS per workgroup (LDS-staged object tables, AA sample store)                  */
     uint32_t tiles_per_workgroup; /* tiles one workgroup renders in sequence (1 unless RTC_TILES_PER_WG says otherwise)   */
-    uint32_t two_tile_workgroups; /* of a launch of several rounds of workgroups the FIRST ones render two tiles each (70 %
-                                     of the tiles, RTC_TILES_SPLIT): a tile's stores drain under the next tile, while the
-                                     launch still ends with single-tile workgroups (a short tail). 0: none               */
+    uint32_t multi_tile_workgroups; /* guided chunks: of a launch of several rounds of workgroups the FIRST ones render four, three,
+                                     then two tiles each (a tile's stores drain under the next one) and the launch ends with
+                                     single-tile workgroups (a short tail); this many render more than one. 0: none
+                                     (RTC_TILES_GUIDED, RTC_TILES_KMAX)                                                  */
     uint32_t _reserved[2];
 } rtc_launch_info;
 rtc_status  rtc_context_last_launch_info(rtc_context *ctx, rtc_launch_info *out);

@@ -559,7 +559,7 @@ class Context:
         return {"source": i.source, "source_name": SOURCE_NAMES.get(i.source, "?"), "reflective": bool(i.reflective),
                 "refractive": bool(i.refractive), "binned_primary_pass": bool(i.binned), "light_lists": bool(i.light_lists),
                 "lane": i.lane, "threads_per_workgroup": i.block, "dynamic_lds_bytes": i.lds_bytes,
-                "tiles_per_workgroup": i.tiles_per_workgroup, "two_tile_workgroups": i.two_tile_workgroups}
+                "tiles_per_workgroup": i.tiles_per_workgroup, "multi_tile_workgroups": i.multi_tile_workgroups}
 
     def binning_times_ms(self, last: int = 1024) -> np.ndarray:
         """Durations (ms) of the binning kernels of the most recent `last` timed launches (0 where a launch had none)."""

@@ -53,7 +53,7 @@ class RtcHit(C.Structure):
 class RtcLaunchInfo(C.Structure):
     _fields_ = [("source", C.c_uint32), ("reflective", C.c_uint32), ("refractive", C.c_uint32), ("binned", C.c_uint32),
                 ("light_lists", C.c_uint32), ("lane", C.c_uint32), ("block", C.c_uint32), ("lds_bytes", C.c_uint32),
-                ("tiles_per_workgroup", C.c_uint32), ("two_tile_workgroups", C.c_uint32), ("_reserved", C.c_uint32 * 2)]
+                ("tiles_per_workgroup", C.c_uint32), ("multi_tile_workgroups", C.c_uint32), ("_reserved", C.c_uint32 * 2)]
 
 
 class RtcLuaJob(C.Structure):

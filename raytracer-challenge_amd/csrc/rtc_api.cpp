@@ -269,9 +269,13 @@ rtc_status rtc_context_create(int32_t device, void *stream, rtc_context **out) {
         const int v = std::atoi(e);
         if (v >= 1 && v <= 16) ctx->tiles_per_wg = (uint32_t)v;
     }
-    if (const char *e = std::getenv("RTC_TILES_SPLIT")) { // per cent of a launch's tiles rendered two per workgroup (RenderParams::split)
+    if (const char *e = std::getenv("RTC_TILES_GUIDED")) { // tenths of `slots` tiles per chunk level (RenderParams::chunk_wgs); 0 = off
         const long v = std::strtol(e, nullptr, 10);
-        if (v >= 0 && v <= 100) ctx->tiles_split_pct = (uint32_t)v;
+        if (v >= 0 && v <= 1000) ctx->tiles_guided_tenths = (uint32_t)v;
+    }
+    if (const char *e = std::getenv("RTC_TILES_KMAX")) {
+        const long v = std::strtol(e, nullptr, 10);
+        if (v >= 1 && v <= 8) ctx->tiles_kmax = (uint32_t)v;
     }
     if (const char *e = std::getenv("RTC_TILE_CAP")) {
         const int v = std::atoi(e);
@@ -802,13 +806,40 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     if (src != SRC_CULL && src != SRC_CULL2) HIP_TRY(rtc_launch_prep(w->d_isect, w->d_prim, w->n, P.views[0].vinv, stream));
     P.total_blocks = P.grid_x * P.grid_y * nviews;
     P.reps = ctx->tiles_per_wg;
-    // (only launches of several rounds of workgroups: a launch the chip holds at once would just get a longer critical path)
-    P.split = (P.reps == 1u && P.total_blocks >= 8192u) ? (uint32_t)((unsigned long long)P.total_blocks * ctx->tiles_split_pct / 200u) : 0u;
-    HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.split ? P.total_blocks - P.split : (P.total_blocks + P.reps - 1u) / P.reps, lds_bytes, stream,
+    // Guided chunks (RenderParams::chunk_wgs): with `slots` workgroups resident at once, the launch's last f x slots tiles go one
+    // per workgroup, the f x slots before them two, then three, four, and everything earlier eight (f = RTC_TILES_GUIDED
+    // tenths, default 2.0; 0 = off; the largest chunk = RTC_TILES_KMAX). Launches of fewer than 3 rounds of workgroups are left alone.
+    P.chunk_wgs[0] = P.chunk_wgs[1] = P.chunk_wgs[2] = P.chunk_wgs[3] = 0u;
+    uint32_t grid_wgs = (P.total_blocks + P.reps - 1u) / P.reps;
+    {
+        static const uint32_t sizes[5] = {1u, 2u, 3u, 4u, 8u}; // chunk sizes from the END of the launch backwards
+        const uint32_t slots = block <= 64u ? 4096u : 1024u * 5u / (block / 64u);
+        const unsigned long long per_level = (unsigned long long)slots * ctx->tiles_guided_tenths / 10u;
+        uint32_t nlevels = 1;
+        while (nlevels < 5u && sizes[nlevels] <= ctx->tiles_kmax) ++nlevels;
+        // Not for a large world on a small frame (C3: 10 000 spheres at 1080p): there the NEXT launch's binning kernel is as long
+        // as this render kernel, and its few waves wait for slots that long-lived workgroups free late — the solo kernel gains
+        // 6 %, the pipelined frame loses 9 % (profiles/r03_exp_tiles_per_workgroup.log).
+        const bool heavy_binning = w->n > 4096u && launch_pixels < 8000000ull;
+        if (P.reps == 1u && per_level != 0u && nlevels > 1u && P.total_blocks >= 3u * slots && !heavy_binning) {
+            unsigned long long rest = P.total_blocks, tiles[5] = {0, 0, 0, 0, 0};
+            for (uint32_t l = 0; l < nlevels && rest; ++l) {
+                unsigned long long tk = (l + 1u == nlevels) ? rest : std::min<unsigned long long>(rest, per_level);
+                if (l) tk -= tk % sizes[l];          // whole workgroups; what does not divide joins the single-tile level
+                tiles[l] = tk;
+                rest -= tk;
+            }
+            tiles[0] += rest;
+            P.chunk_wgs[0] = (uint32_t)(tiles[4] / 8u); P.chunk_wgs[1] = (uint32_t)(tiles[3] / 4u);
+            P.chunk_wgs[2] = (uint32_t)(tiles[2] / 3u); P.chunk_wgs[3] = (uint32_t)(tiles[1] / 2u);
+            grid_wgs = P.chunk_wgs[0] + P.chunk_wgs[1] + P.chunk_wgs[2] + P.chunk_wgs[3] + (uint32_t)tiles[0];
+        }
+    }
+    HIP_TRY(rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, grid_wgs, lds_bytes, stream,
                              timed ? pair[0] : nullptr, timed ? pair[1] : nullptr));
     if (binset) HIP_TRY(hipEventRecord(binset->traced, ctx->stream));
     ctx->last = rtc_launch_info{(uint32_t)src, (w->any_refl || w->any_refr) ? 1u : 0u, w->any_refr ? 1u : 0u, P.tile_cnt ? 1u : 0u,
-                                P.light_cnt ? 1u : 0u, lane, block, (uint32_t)lds_bytes, P.reps, P.split, {0u, 0u}};
+                                P.light_cnt ? 1u : 0u, lane, block, (uint32_t)lds_bytes, P.reps, P.chunk_wgs[0] + P.chunk_wgs[1] + P.chunk_wgs[2] + P.chunk_wgs[3], {0u, 0u}};
     ++ctx->launches_total;
     // rtc_stats::pixels is known here (the kernel traces exactly the pixels of this launch's rows; Camera::render leaves the
     // last row and column alone, camera.rs:120-121): counted on the host, one atomic per wave less
@@ -1213,7 +1244,7 @@ rtc_status rtc_color_at(rtc_context *ctx, const rtc_world *w, const double *rays
         P.flags = flags;
         P.total_blocks = P.grid_x;
         P.reps = 1;
-        P.split = 0;
+        P.chunk_wgs[0] = P.chunk_wgs[1] = P.chunk_wgs[2] = P.chunk_wgs[3] = 0;
         if (rtc_launch_trace(&P, src, w->any_refl || w->any_refr, w->any_refr, P.grid_x, lds_bytes, ctx->stream, nullptr,
                              nullptr) != hipSuccess)
             st = RTC_ERR_DEVICE;

@@ -197,8 +197,10 @@ struct RenderParams {
     uint32_t flags;          // RTC_FLAG_*
     uint32_t total_blocks;   // tiles (x views) of the launch; a workgroup renders tiles blockIdx.x + k * gridDim.x, k < reps
     uint32_t reps;
-    uint32_t split;          // > 0: workgroups [0, split) render TWO tiles (b and split + b), the others one (b + split): the last workgroups of the
-                             // launch are single-tile ones, so a lone launch's tail stays one tile long (RTC_TILES_SPLIT)
+    uint32_t chunk_wgs[4];   // guided chunks: the first chunk_wgs[0] workgroups render EIGHT tiles each, the next chunk_wgs[1] four, then
+                             // chunk_wgs[2] three, chunk_wgs[3] two, the rest one — tile ids ascending in that order, a workgroup's tiles one level-stride apart. A
+                             // tile's stores drain under the workgroup's next tile and the per-wave set-up is shared, while the launch ENDS
+                             // with single-tile workgroups: a lone launch's tail stays one tile long. All zero: `reps` tiles for everyone.
     uint32_t band_stride;    // tile row k of the grid renders image rows y0 + 8*k*band_stride .. (+8) and
                              // writes output rows 8*k .. (+8): 1 = a contiguous range of rows, N = every
                              // N-th band of 8 rows (interleaved row tiles, rtc_render_bands)

@@ -36,7 +36,8 @@ struct rtc_context {
     size_t canvas8_bytes = 0;
     int force_src = -1;   // RTC_SRC env override (experiments)
     uint32_t tiles_per_wg = 1; // tiles one workgroup renders in sequence (RTC_TILES_PER_WG)
-    uint32_t tiles_split_pct = 70; // per cent of a launch's tiles rendered two per workgroup, by its FIRST workgroups (RTC_TILES_SPLIT)
+    uint32_t tiles_guided_tenths = 20; // guided chunks: tiles per chunk level in tenths of the resident workgroups (RTC_TILES_GUIDED; 0 = off)
+    uint32_t tiles_kmax = 8;           // ... largest chunk (RTC_TILES_KMAX: 1, 2, 3, 4 or 8)
     uint32_t tile_cap = 512;
     hipStream_t side_stream = nullptr; // created on demand: per-render binning kernels run here, beside the previous launch's render
     // Pipelined launches (rtc_context_set_pipeline, include/rtc.h): `lanes` > 1 deals consecutive render launches round-robin

@@ -1160,11 +1160,20 @@ k_trace(const RenderParams P_arg, const DevIsect *__restrict__ t_isect, const ui
     // A workgroup renders `reps` tiles, one after the other: tile ids blockIdx.x, blockIdx.x + gridDim.x, ... (consecutive
     // workgroups still land on consecutive XCDs). The canvas stores of tile k then drain while tile k+1 is traced (a wave cannot
     // retire before its stores are acknowledged), and the per-wave set-up and the counter atomics are paid once per `reps` tiles.
-    const uint32_t split = PROBE ? 0u : P.split;
-    const uint32_t reps = PROBE ? 1u : (split ? (blockIdx.x < split ? 2u : 1u) : P.reps);
+    uint32_t wg_reps = PROBE ? 1u : P.reps, wg_base = blockIdx.x, wg_stride = gridDim.x;
+    if (!PROBE && (P.chunk_wgs[0] | P.chunk_wgs[1] | P.chunk_wgs[2] | P.chunk_wgs[3])) { // guided chunks (RenderParams::chunk_wgs)
+        const uint32_t n8 = P.chunk_wgs[0], n4 = P.chunk_wgs[1], n3 = P.chunk_wgs[2], n2 = P.chunk_wgs[3];
+        uint32_t b = blockIdx.x;
+        if (b < n8) { wg_reps = 8u; wg_base = b; wg_stride = n8; }
+        else if ((b -= n8) < n4) { wg_reps = 4u; wg_base = 8u * n8 + b; wg_stride = n4; }
+        else if ((b -= n4) < n3) { wg_reps = 3u; wg_base = 8u * n8 + 4u * n4 + b; wg_stride = n3; }
+        else if ((b -= n3) < n2) { wg_reps = 2u; wg_base = 8u * n8 + 4u * n4 + 3u * n3 + b; wg_stride = n2; }
+        else { wg_reps = 1u; wg_base = 8u * n8 + 4u * n4 + 3u * n3 + 2u * n2 + (b - n2); wg_stride = 0u; }
+    }
+    const uint32_t reps = wg_reps;
     for (uint32_t rep = 0; rep < reps; ++rep) {
     // workgroup id -> tile: see RTC_TILE_ORDER (XCD balance beats XCD locality here)
-    uint32_t bid = split ? ((rep == 0u && blockIdx.x < split) ? blockIdx.x : blockIdx.x + split) : blockIdx.x + rep * gridDim.x;
+    uint32_t bid = wg_base + rep * wg_stride;
     if (!PROBE && bid >= P.total_blocks) break; // (workgroup-uniform)
 #if RTC_TILE_ORDER == 0
     {
