@@ -37,6 +37,7 @@ struct rtc_context {
     int force_src = -1;   // RTC_SRC env override (experiments)
     uint32_t tiles_per_wg = 1; // tiles one workgroup renders in sequence (RTC_TILES_PER_WG)
     uint32_t tiles_guided_tenths = 20; // guided chunks: tiles per chunk level in tenths of the resident workgroups (RTC_TILES_GUIDED; 0 = off)
+    uint32_t tiles_slots = 0;          // 0: from the kernel's occupancy; else the number of resident workgroups to assume (RTC_TILES_SLOTS, tests)
     uint32_t tiles_kmax = 8;           // ... largest chunk (RTC_TILES_KMAX: 1, 2, 3, 4 or 8)
     uint32_t tile_cap = 512;
     hipStream_t side_stream = nullptr; // created on demand: per-render binning kernels run here, beside the previous launch's render

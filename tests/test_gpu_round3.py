@@ -429,3 +429,65 @@ def test_lua_program_render_orbit_animation(rtc, scenes, O):
         assert np.array_equal(decode_png(paths[3].read_bytes()), frames[3])
         assert paths[5].read_bytes() == rtc.format_ppm_rgb8(frames[5])
     ctx.close()
+
+
+def test_guided_chunks_render_the_same_frames(rtc, scenes):
+    """Guided chunks (RenderParams::chunk_wgs): a launch's first workgroups render eight, four, three, two tiles each and its last
+    ones one — only the tile -> workgroup mapping changes, so canvases, 8-bit frames and ray counts must equal the one-tile-per-
+    workgroup launch bit for bit. RTC_TILES_SLOTS makes small launches take every chunk level (the real threshold is three
+    rounds of workgroups): flat, reflective, glass, anti-aliased, two-level worlds; rows, one rank's bands, several views;
+    Camera::render's exclusive edge; a frame whose tile count divides by none of the chunk sizes."""
+    import torch
+    M = rtc.Matrix
+    cases = []
+    for kind in ("flat", "reflective", "glass", "large", "aa"):
+        W, H = (331, 203) if kind != "aa" else (160, 96)
+        if kind == "glass":
+            w, cam = scenes.glass_cluster(30, W, H)
+        else:
+            w, cam = scenes.synthetic(700 if kind == "large" else 50, W, H, reflective=(kind == "reflective"))
+        if kind == "aa":
+            cam.samples = 4
+        cases.append((kind, w, cam))
+    for kind, w, cam in cases:
+        W, H = cam.hsize, cam.vsize
+        ref_ctx = _ctx_env(rtc, RTC_TILES_GUIDED=0)
+        dref = ref_ctx.upload(w)
+        want = {m: dref.render(cam, m, with_stats=True) for m in (rtc.MODE_RENDER_ASYNC, rtc.MODE_RENDER)}
+        assert ref_ctx.last_launch_info()["multi_tile_workgroups"] == 0
+        for slots, kmax in ((5, 8), (16, 4), (3, 2)):
+            ctx = _ctx_env(rtc, RTC_TILES_SLOTS=slots, RTC_TILES_KMAX=kmax, RTC_BIN_SMALL_PIXELS=0)
+            dw = ctx.upload(w)
+            for mode, (img, st) in want.items():
+                f = torch.full((H, W, 3), -1.0, dtype=torch.float64, device="cuda:0")
+                q = torch.full((H, W, 3), 9, dtype=torch.uint8, device="cuda:0")
+                torch.cuda.synchronize()
+                ctx.reset_stats()
+                dw.render_rows(cam, 0, H, f.data_ptr(), mode, d_ptr8=q.data_ptr())
+                got_st = ctx.stats(extended=True)
+                assert ctx.last_launch_info()["multi_tile_workgroups"] > 0, (kind, slots, kmax)
+                assert np.array_equal(f.cpu().numpy(), img) and all(got_st[k] == st[k] for k in st if k in got_st), (kind, slots, kmax, mode, got_st, st)
+                assert np.array_equal(q.cpu().numpy(), rtc.color_scale255(img).reshape(H, W, 3)), (kind, slots, kmax, mode)
+            # one rank's bands (rank 1 of 3) and three views in one launch
+            per = rtc.group_packed_rows(H, 3)
+            t = torch.zeros((per, W, 3), dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()
+            dw.render_bands(cam, 1, 3, t.data_ptr())
+            ctx.synchronize()
+            got = t.cpu().numpy()
+            full = want[rtc.MODE_RENDER_ASYNC][0]
+            for k in range(rtc.group_bands_owned(H, 3, 1)):
+                y0 = rtc.group_packed_row_to_image(1, 8 * k, 3)
+                assert np.array_equal(got[8 * k: 8 * k + min(8, H - y0)], full[y0:y0 + 8]), (kind, slots, k)
+            HP = -(-H // 8) * 8
+            v = torch.zeros((3 * HP, W, 3), dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()
+            dw.render_views([cam, cam, cam], 0, 1, v.data_ptr(), HP)
+            ctx.synchronize()
+            vh = v.cpu().numpy()
+            for k in range(3):
+                assert np.array_equal(vh[k * HP: k * HP + H], full), (kind, slots, "view", k)
+            dw.close()
+            ctx.close()
+        dref.close()
+        ref_ctx.close()
