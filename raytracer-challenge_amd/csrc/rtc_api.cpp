@@ -817,7 +817,7 @@ static rtc_status render_launch(rtc_context *ctx, const rtc_world *w, const rtc_
     uint32_t grid_wgs = (P.total_blocks + P.reps - 1u) / P.reps;
     {
         static const uint32_t sizes[5] = {1u, 2u, 3u, 4u, 8u}; // chunk sizes from the END of the launch backwards
-        const uint32_t slots = ctx->tiles_slots ? ctx->tiles_slots : (block <= 64u ? 4096u : 1024u * 5u / (block / 64u));
+        const uint32_t slots = ctx->tiles_slots ? ctx->tiles_slots : (1024u * ((w->any_refl || w->any_refr) ? 4u : 5u) / std::max(1u, block / 64u));
         const unsigned long long per_level = (unsigned long long)slots * ctx->tiles_guided_tenths / 10u;
         uint32_t nlevels = 1;
         while (nlevels < 5u && sizes[nlevels] <= ctx->tiles_kmax) ++nlevels;

@@ -134,9 +134,13 @@ enum { RTC_MAX_VIEWS = 8 };
 #ifndef RTC_BLOCK_CULL2
 #define RTC_BLOCK_CULL2 64 // large worlds, flat kernel: C3 0.106 -> 0.102 ms against 128 (profiles/r02_exp_block_size.log)
 #endif
+#ifndef RTC_BLOCK_CULL1
+#define RTC_BLOCK_CULL1 64 // small worlds, flat kernel, since the guided chunks (a workgroup renders several tiles): one wave per workgroup
+                           // 0.0576 -> 0.0561 ms pipelined, 0.0581 -> 0.0566 solo against 128 (north star; C2 -2.4 %); before the chunks: -1 %
+#endif
 #define RTC_BLOCK_FOR(cull, refl, refr, probe) \
     (((refl) || (refr)) ? (RTC_COMPACT_FOR(cull, refl, refr, probe) ? 128 : RTC_BLOCK_STACK) \
-                        : ((cull) == 2 && !(probe) ? RTC_BLOCK_CULL2 : RTC_BLOCK))
+                        : ((cull) == 2 && !(probe) ? RTC_BLOCK_CULL2 : ((cull) == 1 && !(probe) ? RTC_BLOCK_CULL1 : RTC_BLOCK)))
 #define RTC_TILE_W_FOR(cull, refl, refr, probe) ((RTC_BLOCK_FOR(cull, refl, refr, probe) / 64u) * 8u)
 
 // Tile-list entries hold (key >> 16) << 16 | index while every index fits 16 bits

@@ -444,7 +444,7 @@ def test_bench_single_gpu_line():
     rf = line["roofline"]
     assert rf["frames_per_launch"] == 1 and rf["kernel_launches_timed"] == 24 and 0 < rf["frac"] < 1
     assert rf["algorithmic_bytes_per_launch"] == 24 * 640 * 360 + 400 * 101 + 128 + 200
-    assert line["launch"]["source"] == 3 and line["launch"]["threads_per_workgroup"] == 128
+    assert line["launch"]["source"] == 3 and line["launch"]["threads_per_workgroup"] == 64
     assert line["serial_single_view"]["value"] > 0 and line["serial_single_view"]["launch"]["lane"] == 0
     assert line["batched_views"]["frames_per_launch"] == 8 and line["batched_views"]["value"] > 0
     bf = line["brute_force_lds"]
